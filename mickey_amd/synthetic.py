@@ -1,0 +1,209 @@
+"""Seeded synthetic weights and inputs for the MicKey hot path.
+
+There are no pretrained weights or Map-free data on the build/GPU boxes, so parity tests and
+``bench.py`` run on seeded random weights laid out EXACTLY like a reference checkpoint
+(key names / shapes: SURVEY.md §8(b) "Checkpoint contract", probed from the reference's own
+``state_dict()``), so the same dict loads into the reference model (``load_state_dict(strict=True)``),
+into the CPU oracle and into the HIP path.
+
+Generation uses an explicit CPU ``torch.Generator`` in a fixed key order, so the weights are
+bit-identical on every box with the same torch build.  BatchNorm running stats and the dustbin
+score are randomised (identity BN would make head tests weak).
+"""
+import math
+
+import torch
+
+VIT_ARCH = {
+    # name: (embed_dim, depth, heads)   (reference DINO_modules/dinov2.py:306-345)
+    "vit_tiny_test": (128, 2, 2),
+    "vit_small": (384, 12, 6),
+    "vit_base": (768, 12, 12),
+    "vit_large": (1024, 24, 16),
+}
+
+HEADS = ("det_head", "det_offset", "depth_head", "dsc_head")
+EXTRACTOR_PREFIX = "compute_matches.extractor."
+DINO_PREFIX = EXTRACTOR_PREFIX + "dinov2_vitl14."
+DUSTBIN_KEY = "compute_matches.matcher.matching_mat.dustbin_score"
+
+
+def _randn(g, shape, std=1.0, mean=0.0):
+    return torch.randn(shape, generator=g, dtype=torch.float32) * std + mean
+
+
+def _rand(g, shape, lo, hi):
+    return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def dinov2_state_dict(arch="vit_large", seed=0, prefix="", pos_grid=37):
+    """Random DINOv2 ViT/14 weights with the hub file's key layout (reference
+    DINO_modules/dinov2.py:88-150).  ``pos_grid``=37 is img_size 518 / 14."""
+    D, depth, _ = VIT_ARCH[arch]
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    sd[prefix + "cls_token"] = _randn(g, (1, 1, D), 0.02)
+    sd[prefix + "pos_embed"] = _randn(g, (1, 1 + pos_grid * pos_grid, D), 0.02)
+    sd[prefix + "mask_token"] = torch.zeros(1, D)
+    sd[prefix + "patch_embed.proj.weight"] = _randn(g, (D, 3, 14, 14), 1.0 / math.sqrt(588.0))
+    sd[prefix + "patch_embed.proj.bias"] = _randn(g, (D,), 0.02)
+    for i in range(depth):
+        p = prefix + "blocks.%d." % i
+        sd[p + "norm1.weight"] = _randn(g, (D,), 0.1, 1.0)
+        sd[p + "norm1.bias"] = _randn(g, (D,), 0.02)
+        sd[p + "attn.qkv.weight"] = _randn(g, (3 * D, D), 1.0 / math.sqrt(D))
+        sd[p + "attn.qkv.bias"] = _randn(g, (3 * D,), 0.02)
+        sd[p + "attn.proj.weight"] = _randn(g, (D, D), 1.0 / math.sqrt(D))
+        sd[p + "attn.proj.bias"] = _randn(g, (D,), 0.02)
+        sd[p + "ls1.gamma"] = _rand(g, (D,), 0.05, 0.3)
+        sd[p + "norm2.weight"] = _randn(g, (D,), 0.1, 1.0)
+        sd[p + "norm2.bias"] = _randn(g, (D,), 0.02)
+        sd[p + "mlp.fc1.weight"] = _randn(g, (4 * D, D), 1.0 / math.sqrt(D))
+        sd[p + "mlp.fc1.bias"] = _randn(g, (4 * D,), 0.02)
+        sd[p + "mlp.fc2.weight"] = _randn(g, (D, 4 * D), 1.0 / math.sqrt(4 * D))
+        sd[p + "mlp.fc2.bias"] = _randn(g, (D,), 0.02)
+        sd[p + "ls2.gamma"] = _rand(g, (D,), 0.05, 0.3)
+    sd[prefix + "norm.weight"] = _randn(g, (D,), 0.1, 1.0)
+    sd[prefix + "norm.bias"] = _randn(g, (D,), 0.02)
+    return sd
+
+
+def _basic_block(g, sd, p, cin, cout):
+    sd[p + "conv1.weight"] = _randn(g, (cout, cin, 3, 3), math.sqrt(2.0 / (9 * cin)))
+    sd[p + "conv2.weight"] = _randn(g, (cout, cout, 3, 3), math.sqrt(2.0 / (9 * cout)))
+    for bn in ("bn1.", "bn2."):
+        sd[p + bn + "weight"] = _rand(g, (cout,), 0.5, 1.5)
+        sd[p + bn + "bias"] = _randn(g, (cout,), 0.1)
+        sd[p + bn + "running_mean"] = _randn(g, (cout,), 0.1)
+        sd[p + bn + "running_var"] = _rand(g, (cout,), 0.5, 1.5)
+        sd[p + bn + "num_batches_tracked"] = torch.tensor(100, dtype=torch.long)
+    if cin != cout:
+        sd[p + "shortcut.0.weight"] = _randn(g, (cout, cin, 1, 1), math.sqrt(1.0 / cin))
+
+
+def heads_state_dict(cfg, seed=0, prefix=EXTRACTOR_PREFIX):
+    """Random head weights with the reference's key layout (reference mickey_extractor.py:67-251,
+    extractor_utils.py:12-26, att_layers/transformer_utils.py:14-38)."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    mk = cfg["MICKEY"]
+    cin = mk["DINOV2"]["CHANNEL_DIM"]
+    dims = list(mk["KP_HEADS"]["BLOCKS_DIM"])
+    sd = {}
+    for head in HEADS:
+        hp = prefix + head + "."
+        last = mk["DSC_HEAD"]["LAST_DIM"] if head == "dsc_head" else dims[3]
+        chain = [cin, dims[0], dims[1], dims[2], last]
+        for b in range(4):
+            _basic_block(g, sd, hp + "resblock%d." % (b + 1), chain[b], chain[b + 1])
+        d = dims[2]
+        for l in range(3):
+            lp = hp + "att_layer.layers.%d." % l
+            for nm in ("q_proj", "k_proj", "v_proj", "merge"):
+                sd[lp + nm + ".weight"] = _randn(g, (d, d), 1.0 / math.sqrt(d))
+            sd[lp + "mlp.0.weight"] = _randn(g, (2 * d, 2 * d), 1.0 / math.sqrt(2 * d))
+            sd[lp + "mlp.2.weight"] = _randn(g, (d, 2 * d), 1.0 / math.sqrt(2 * d))
+            for nm in ("norm1", "norm2"):
+                sd[lp + nm + ".weight"] = _randn(g, (d,), 0.1, 1.0)
+                sd[lp + nm + ".bias"] = _randn(g, (d,), 0.05)
+        if head == "det_head":
+            sd[hp + "score.weight"] = _randn(g, (1, last, 1, 1), 4.0)
+            sd[hp + "eps"] = torch.tensor(1e-16)
+            sd[hp + "offset_par1"] = torch.tensor(0.5)
+            sd[hp + "offset_par2"] = torch.tensor(2.0)
+            sd[hp + "ones_kernel"] = torch.ones(1, 1, 3, 3)
+        elif head == "det_offset":
+            sd[hp + "xy_offset.weight"] = _randn(g, (2, last, 1, 1), 0.3)
+        elif head == "depth_head":
+            sd[hp + "depth.weight"] = _randn(g, (1, last, 1, 1), 0.3).abs()
+    return sd
+
+
+def mickey_state_dict(cfg, seed=0, arch="vit_large", dustbin=1.0):
+    """Full synthetic checkpoint ``state_dict`` (DINOv2 keys included)."""
+    sd = {}
+    sd.update(dinov2_state_dict(arch, seed, prefix=DINO_PREFIX))
+    sd.update(heads_state_dict(cfg, seed))
+    if cfg["FEATURE_MATCHER"]["TYPE"] == "DualSoftmax":
+        if cfg["FEATURE_MATCHER"]["DUAL_SOFTMAX"]["USE_DUSTBIN"]:
+            sd[DUSTBIN_KEY] = torch.tensor(float(dustbin))
+    else:
+        sd[DUSTBIN_KEY] = torch.tensor(float(dustbin))
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# inputs
+
+TOY_K0 = [[549.7018, 0.0, 268.6665], [0.0, 549.7018, 351.8357], [0.0, 0.0, 1.0]]
+TOY_K1 = [[549.0616, 0.0, 268.8559], [0.0, 549.0616, 351.8485], [0.0, 0.0, 1.0]]
+
+
+def synthetic_batch(B=1, H=720, W=540, seed=1234):
+    """SURVEY.md §8(d) throughput batch: uniform images in [0,1), toy-example intrinsics
+    (reference data/toy_example/intrinsics.txt)."""
+    g0 = torch.Generator().manual_seed(seed)
+    g1 = torch.Generator().manual_seed(seed + 1)
+    return {
+        "image0": torch.rand((B, 3, H, W), generator=g0),
+        "image1": torch.rand((B, 3, H, W), generator=g1),
+        "K_color0": torch.tensor(TOY_K0).repeat(B, 1, 1),
+        "K_color1": torch.tensor(TOY_K1).repeat(B, 1, 1),
+    }
+
+
+def planted_pose_problem(B=1, h=51, w=38, seed=4321, inlier_frac=0.6, down=14, angle_deg=(5.0, 10.0),
+                         t_norm=(0.3, 0.4)):
+    """Solver-realism generator: a known relative pose is planted into
+    keypoints/depths and a peaked ``final_scores`` matrix, so a solver that is statistically
+    equivalent to the reference must recover it.  Returns (data dict, R_gt [B,3,3], t_gt [B,1,3])."""
+    g = torch.Generator().manual_seed(seed)
+    n = h * w
+    K0 = torch.tensor(TOY_K0)
+    K1 = torch.tensor(TOY_K1)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], 0)  # [2,n] (x, y)
+    data = {k: [] for k in ("kps0", "kps1", "depth_kp0", "depth_kp1", "final_scores")}
+    Rs, ts = [], []
+    for b in range(B):
+        ang = math.radians(angle_deg[0] + angle_deg[1] * (b % 3))
+        axis = _randn(g, (3,))
+        axis = axis / axis.norm()
+        Kx = torch.tensor([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = torch.eye(3) + math.sin(ang) * Kx + (1 - math.cos(ang)) * (Kx @ Kx)
+        t = _randn(g, (3,))
+        t = t / t.norm() * (t_norm[0] + t_norm[1] * (b % 3))
+        kps0 = (grid + _rand(g, (2, n), 0, 1)) * down
+        d0 = _rand(g, (n,), 1.0, 8.0)
+        uv1 = torch.cat([kps0, torch.ones(1, n)], 0)
+        X0 = d0 * (torch.linalg.inv(K0) @ uv1)  # [3,n]
+        X1 = R @ X0 + t[:, None]
+        proj = K1 @ X1
+        uv = proj[:2] / proj[2:].clamp_min(1e-6)
+        cell = torch.floor(uv / down)
+        valid = (X1[2] > 0.1) & (cell[0] >= 0) & (cell[0] < w) & (cell[1] >= 0) & (cell[1] < h)
+        keep = valid & (torch.rand(n, generator=g) < inlier_frac)
+        j = (cell[1] * w + cell[0]).long().clamp(0, n - 1)
+        # image-1 keypoints / depths: background random, planted cells consistent with (R, t)
+        kps1 = (grid + _rand(g, (2, n), 0, 1)) * down
+        d1 = _rand(g, (n,), 1.0, 8.0)
+        i_idx = torch.nonzero(keep).flatten()
+        # one source per destination cell (last writer wins, then rebuild the list consistently)
+        owner = torch.full((n,), -1, dtype=torch.long)
+        owner[j[i_idx]] = i_idx
+        jj = torch.nonzero(owner >= 0).flatten()
+        ii = owner[jj]
+        kps1[:, jj] = uv[:, ii]
+        d1[jj] = X1[2, ii]
+        fs = _rand(g, (n, n), 0.0, 1e-9)
+        fs[ii, jj] = 1e-6 * (0.5 + torch.rand(len(ii), generator=g))
+        data["kps0"].append(kps0)
+        data["kps1"].append(kps1)
+        data["depth_kp0"].append(d0[None])
+        data["depth_kp1"].append(d1[None])
+        data["final_scores"].append(fs)
+        Rs.append(R)
+        ts.append(t[None])
+    out = {k: torch.stack(v, 0).contiguous() for k, v in data.items()}
+    out["K_color0"] = K0.repeat(B, 1, 1)
+    out["K_color1"] = K1.repeat(B, 1, 1)
+    return out, torch.stack(Rs, 0), torch.stack(ts, 0)
