@@ -1,0 +1,220 @@
+/* mickey_hip.h -- C ABI of libmickey_hip.so: the MI355X (gfx950) kernels behind the MicKey
+ * inference hot path.
+ *
+ * The reference (nianticlabs/mickey) has no native code and no FFI: every GPU op is an ATen call
+ * made from Python.  Each entry point below therefore cites the reference
+ * PYTHON call site(s) (file:line under /root/reference) whose arithmetic it replaces; the Python
+ * binding a maintainer adds on the reference side is shown in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (tensor.data_ptr()), explicit sizes/strides, a stream handle
+ *     (hipStream_t passed as void*); no torch types.
+ *   - every function returns MK_OK (0) or an MK_ERR_* code; mk_last_error() gives the text.
+ *   - functions only enqueue work on `stream`: no allocation, no synchronisation, no host<->device
+ *     copies.  Scratch memory is passed in by the caller (sizes documented per function).
+ *   - re-entrant: no mutable globals besides the thread-local error string.
+ *   - "lp" (low precision) buffers hold bf16 or fp16 according to `dtype` (MK_BF16 / MK_F16);
+ *     accumulation is always fp32.
+ */
+#ifndef MICKEY_HIP_H
+#define MICKEY_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mk_stream_t; /* hipStream_t */
+
+enum { MK_OK = 0, MK_ERR_INVALID_ARGUMENT = 1, MK_ERR_LAUNCH = 2 };
+enum { MK_BF16 = 0, MK_F16 = 1 };
+enum { MK_ACT_NONE = 0, MK_ACT_RELU = 1, MK_ACT_GELU = 2 };
+/* internal epilogue selectors of the GEMM kernel (exposed for tests/tools only) */
+enum { MK_EPI_STORE = 0, MK_EPI_LS_RESIDUAL = 1, MK_EPI_QKV = 2, MK_EPI_PATCH = 3 };
+
+int mk_version(void);
+const char* mk_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder: DINOv2 ViT/14 (reference lib/models/MicKey/modules/DINO_modules/)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias).  A, W lp with K contiguous; out lp or fp32.
+ * Replaces nn.Linear call sites: mlp.fc1+GELU (layers/mlp.py:36-37) and the heads' small linears
+ * (att_layers/transformer_utils.py:55-57,60,64).  K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0. */
+int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldc, int M, int N, int K,
+            int act, int out_is_f32, int dtype, mk_stream_t stream);
+
+/* `groups` independent GEMMs of identical shape in one launch (element strides per group; a stride
+ * of 0 shares the operand).  Used to run the four heads side by side. */
+int mk_gemm_grouped(const void* A, int lda, long long strideA, const void* W, int ldw, long long strideW, const float* bias,
+                    long long strideBias, void* out, int ldc, long long strideOut, int groups, int M, int N, int K, int act,
+                    int out_is_f32, int dtype, mk_stream_t stream);
+
+/* x[M,N] (fp32, in place) += gamma[N] * (A . W^T + bias): attn.proj+ls1+residual and mlp.fc2+ls2+
+ * residual (layers/attention.py:60, mlp.py:39, layer_scale.py:27-28, block.py:105-106). */
+int mk_gemm_ls_residual(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, float* x,
+                        int ldx, int M, int N, int K, int dtype, mk_stream_t stream);
+
+/* attn.qkv (layers/attention.py:51-53): [nimg*ntok, D] x [3D, D]^T + bias, split per head into
+ *   q  [nimg, heads, ntok_pad, 64]  (multiplied by qscale = 64^-0.5 * log2(e): the attention kernel
+ *                                    exponentiates with exp2)
+ *   k  [nimg, heads, ntok_pad, 64]
+ *   vt [nimg, heads, 64, ntok_pad]  V transposed, token index stored with bits 2 and 3 swapped
+ * Pad rows (token >= ntok) are never written: the caller zero-fills q/k/vt once.  head_dim is 64
+ * for every DINOv2 size (S/B/L/g). */
+int mk_gemm_qkv(const void* A, int lda, const void* W, int ldw, const float* bias, void* q, void* k, void* vt, int nimg,
+                int ntok, int ntok_pad, int heads, float qscale, int dtype, mk_stream_t stream);
+
+/* Patch embedding (layers/patch_embed.py:76-78) + pos-embed add (dinov2.py:198): A = im2col rows
+ * [nimg*npatch, K], W = conv weight [D, K]; x[img, 1+p, :] = A.W^T + bias + pos[1+p, :] (fp32). */
+int mk_gemm_patch_embed(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, float* x,
+                        int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream);
+
+/* im2col for the 14x14/stride-14 patch conv.  img fp32 NCHW (3 channels) with explicit element
+ * strides (so the /14 crop of mickey_extractor.py:46 is just a smaller gh/gw); out lp
+ * [nimg*gh*gw, ldo], column ch*196 + dy*14 + dx, columns 588..ldo-1 zero. */
+int mk_im2col_patch14(const float* img, long long stride_img, long long stride_ch, int stride_row, int nimg, int gh,
+                      int gw, void* out, int ldo, int dtype, mk_stream_t stream);
+
+/* x[img, 0, :] = cls + pos[0, :]  (dinov2.py:197-198) */
+int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int ntok, int D, mk_stream_t stream);
+
+/* LayerNorm over the last dim (dinov2.py:87,230; block.py:84,87; transformer_utils.py:37-38).
+ * x fp32 [*, ldx]; output row r reads input row (r / (rows_per_img - skip)) * rows_per_img + skip +
+ * r % (rows_per_img - skip)  (skip = 1 drops the CLS token, dinov2.py:233).  out lp or fp32.
+ * If resid != NULL (fp32 [rows_out, ldr]): resid += LN(x) and `out` receives the updated resid
+ * (transformer_utils.py:64-66). */
+int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int dtype, mk_stream_t stream);
+
+/* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
+ * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
+ * out lp [nimg*ntok, ldo] with column head*64 + d. */
+int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads, int ntok,
+                      int ntok_pad, int dtype, mk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heads (reference lib/models/MicKey/modules/mickey_extractor.py:67-251)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* 3x3 conv, pad 1, as implicit GEMM over NHWC lp activations, BatchNorm folded into W/bias by the
+ * caller (utils/extractor_utils.py:28-35):
+ *   out[g][pix, co] = act( sum_{tap,ci} W[g][co, tap*C1+ci] * in1[g][pix+tap, ci]
+ *                        + sum_{ci} W[g][co, 9*C1+ci] * in2[g][pix, ci]      (1x1 shortcut, optional)
+ *                        + bias[g][co] + resid[g][pix, co] (identity shortcut, optional) )
+ * tap = ky*3+kx.  `zero_page`: >= 128 zero bytes in device memory (source of out-of-image taps).
+ * C1, C2 % 64 == 0; Cout % 4 == 0.  Strides are element strides per group (0 = shared input). */
+int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, long long stride_in2, int C2, const void* W,
+               int ldw, long long strideW, const float* bias, long long strideBias, const void* resid, void* out, int Cout,
+               long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_is_f32, const void* zero_page,
+               int dtype, mk_stream_t stream);
+
+/* Start of Transformer_self_att (att_layers/transformer.py:92-95): xs = x + pe (fp32 stream) and an
+ * lp copy into columns [0,C) of a [rows, ld_cat] buffer.  x lp [G][rows, C]; pe fp32 [npix, C] or NULL. */
+int mk_posenc_add(const void* x, const float* pe, float* xs, void* cat, int ld_cat, int groups, int nimg, int npix, int C,
+                  int dtype, mk_stream_t stream);
+
+/* Linear attention (att_layers/attention.py:46-64), heads of 16 channels.
+ * qkv fp32 [G][nimg*L, 3C] (q | k | v).  Step 1 computes per (g, img, head)
+ *   KV[16][16] = sum_s (elu(k_s)+1) (x) v_s / L   and   Ksum[16] = sum_s (elu(k_s)+1)
+ * into kv fp32 [G*nimg*(C/16)][272], deterministically (per-chunk partials in `work`, then a fixed-
+ * order reduction).  work: mk_linattn_work_floats(G, nimg, L, C) fp32 elements. */
+long long mk_linattn_work_floats(int groups, int nimg, int L, int C);
+int mk_linattn_kv(const float* qkv, float* kv, float* work, int groups, int nimg, int L, int C, mk_stream_t stream);
+/* Step 2: msg[s, h*16+v] = (phi(q_s) . KV[:, v]) * L / (phi(q_s) . Ksum + 1e-6), written lp to
+ * out [G][nimg*L, ldo]. */
+int mk_linattn_apply(const float* qkv, const float* kv, void* out, int ldo, int groups, int nimg, int L, int C, int dtype,
+                     mk_stream_t stream);
+
+/* Head tails (mickey_extractor.py:134-138,173-176,213-216,246-249 and
+ * compute_correspondences.py:20-31).  feat* fp32 [nimg*h*w, C] (resblock4 outputs).
+ *   scr   [nimg, h*w]      border-masked temperature-100 softmax (or sigmoid) of w_score . feat_det
+ *   kps   [nimg, 2, h*w]   (sigmoid(w_xy . feat_off) + cell) * down   (x row, then y row)
+ *   depth [nimg, h*w]      w_depth . feat_depth  (max_depth * sigmoid(.) if use_depth_sigmoid)
+ *   dsc   [nimg, Cd, h*w]  feat_dsc / sqrt(sum_c feat_dsc^2 + 1e-10) if norm_dsc, transposed */
+int mk_head_tails(const float* feat_det, const float* w_score, const float* feat_off, const float* w_xy,
+                  const float* feat_depth, const float* w_depth, const float* feat_dsc, float* scr, float* kps, float* depth,
+                  float* dsc, int nimg, int h, int w, int C, int Cd, int border, int use_softmax, int use_depth_sigmoid,
+                  float max_depth, int norm_dsc, float down, mk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher (reference lib/models/MicKey/modules/utils/feature_matcher.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* dualSoftmax.forward (feature_matcher.py:64-83) + kp_matrix_scores (compute_correspondences.py:46-50)
+ * + final_scores (compute_pose.py:23), exact-fp32 MFMA correlation.
+ *   dsc0 [B, C, n0], dsc1 [B, C, n1] fp32;  scr0 [B, n0], scr1 [B, n1] fp32 (may be NULL with kp/final NULL)
+ *   scores / kp_scores / final_scores [B, n0, n1] fp32, each may be NULL (lean mode).
+ *   use_dustbin: append the scalar `dustbin` as extra row/column/corner before both softmaxes.
+ *   work: fp32 scratch, mk_dual_softmax_work_floats(B, n0, n1) elements. */
+long long mk_dual_softmax_work_floats(int B, int n0, int n1);
+int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
+                    int use_dustbin, float dustbin, float* scores, float* kp_scores, float* final_scores, float* work, int B,
+                    int C, int n0, int n1, mk_stream_t stream);
+
+/* sinkhorn.forward (feature_matcher.py:93-137): 10 log-domain iterations on u, v only.
+ *   work: mk_sinkhorn_work_floats(B, n0, n1) fp32 elements (holds the (n0+1)x(n1+1) coupling matrix). */
+long long mk_sinkhorn_work_floats(int B, int n0, int n1);
+int mk_sinkhorn(const float* dsc0, const float* dsc1, float alpha, int iters, float* scores, float* work, int B, int C,
+                int n0, int n1, mk_stream_t stream);
+
+/* featureMatcher.get_matches_list (feature_matcher.py:19-46), batched: mutual nearest neighbours on
+ * scores[b, :n0-1, :n1-1], sorted by score descending.  matches int32 [B, n0, 2] (row i, col j),
+ * count int32 [B].  work: 2*B*(n0+n1) ints. */
+int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B, int n0, int n1, mk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Probabilistic Procrustes solver (reference .../utils/probabilisticProcrustes.py:183-348)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Weighted sampling without replacement == top-k of p / Exp(1) ("exponential race"); what
+ * torch.multinomial(p, k) computes (probabilisticProcrustes.py:230-231).  For every pair b and every
+ * r in [0, rows_per_pair): idx[b*rows_per_pair + r, 0..k) = indices of the k largest p[b, c] / e[b, r, c],
+ * in descending key order (the order torch.topk returns).
+ *   p      [B, ncell] fp32, >= 0
+ *   noise  NULL: e drawn on device from Philox4x32-10(seed, offset); else fp32 [B*rows_per_pair, ncell]
+ *          injected Exp(1) draws (tests: bit-comparable with torch)
+ *   idx    int32 [B*rows_per_pair, k];  cnt int32 [B*rows_per_pair] = number of non-zero-key entries
+ *          actually available (< k only if fewer than k cells have p > 0; the tail is then filled
+ *          with zero-probability cells in ascending index order)
+ *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k) */
+long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k);
+int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx,
+                    int* cnt, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream);
+
+/* Index decode + gathers + back-projection (probabilisticProcrustes.py:233-244, training_utils.py:7-22):
+ * for every sampled cell c = idx[r, s]: i = c / n1 (image-0 keypoint), j = c % n1;
+ *   X[r, s, :] = depth0[b, i] * K0[b]^-1 [kps0[b, :, i], 1],  Y likewise from image 1,
+ *   wts[r, s] = final_scores[b, c],  corr[r, s, :] = (u0, v0, u1, v1, d0, d1)   (for the inlier list)
+ * kps [B, 2, n], depth [B, n], K [B, 3, 3] fp32.  r = b*rows_per_pair + o. */
+int mk_gather_backproject(const int* idx, const float* final_scores, const float* kps0, const float* depth0,
+                          const float* kps1, const float* depth1, const float* K0, const float* K1, float* X, float* Y,
+                          float* wts, float* corr, int B, int rows_per_pair, int k, int n0, int n1, mk_stream_t stream);
+
+/* Hypothesis generation and scoring (probabilisticProcrustes.py:247-268; loss/solvers.py:31-52;
+ * training_utils.py:55-61).  For every correspondence set r (k points) and every h in [0, it_ransac):
+ * draw 3 of k without replacement weighted by wts (exponential race; noise3 = NULL: Philox, else fp32
+ * [R*it_ransac, k] injected; idx3_in != NULL injects the 3 indices directly), fit R,t by Kabsch on the
+ * 3 point pairs, score = sum_j sigmoid(5/th * (th - sqrt(|R X_j + t - Y_j|^2 + 1e-6))).
+ *   Rh [R*it_ransac, 9], th [R*it_ransac, 3], score [R*it_ransac], idx3 int32 [R*it_ransac, 3] (out) */
+int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
+                         unsigned long long seed, unsigned long long offset, float th_soft, float* Rh, float* th,
+                         float* score, int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream);
+
+/* Arg-max over a pair's hypotheses, <= num_ref rounds of {hard-inlier recount, masked weighted Kabsch},
+ * final confidence (probabilisticProcrustes.py:275-303, loss/solvers.py:13-26, training_utils.py:71-75).
+ * One workgroup per pair.  hyp_per_pair = it_matches*it_ransac; the winning set is best / it_ransac.
+ *   R [B, 9], t [B, 3], conf [B], best int32 [B], inl_mask uint8 [B, k] (hard inliers of the final pose),
+ *   rounds int32 [B] (refits done), invalid int32 [1]: set to 1 if any hypothesis of the BATCH is
+ *   non-finite (the reference then zeroes the whole batch, :261-262,329-342; applied by mk_pose_finalize). */
+int mk_refine_pose(const float* X, const float* Y, const float* Rh, const float* th, const float* score, float th_inlier,
+                   int num_ref, int min_inliers, float* R, float* t, float* conf, int* best, unsigned char* inl_mask,
+                   int* rounds, int* invalid, int B, int it_matches, int it_ransac, int k, mk_stream_t stream);
+
+/* If *invalid != 0: zero R, t, conf for the whole batch (reference :338-342). */
+int mk_pose_finalize(float* R, float* t, float* conf, const int* invalid, int B, mk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICKEY_HIP_H */

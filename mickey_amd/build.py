@@ -1,0 +1,89 @@
+"""Build libmickey_hip.so (gfx950) in-tree with hipcc.
+
+    python -m mickey_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects are rebuilt only when a source (or a header)
+is newer; the shared library lands in mickey_amd/lib/ and travels with the repo snapshot to the GPU
+box (it is git-ignored, not gpurun-ignored).
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIBNAME = "libmickey_hip.so"
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, save_temps=False, verbose=True):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    if not srcs:
+        raise RuntimeError("no .hip sources under %s" % CSRC)
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_time = _newest(hdrs) if hdrs else 0.0
+    cc = hipcc()
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+             "-I", INCLUDE]
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            cmd = [cc] + flags + ["-c", s, "-o", o]
+            if save_temps:
+                cmd.insert(1, "-save-temps=obj")
+            jobs.append((s, cmd))
+
+    def run(job):
+        s, cmd = job
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=OBJDIR)
+        return s, r.returncode, r.stdout
+
+    failed = False
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for s, rc, out in ex.map(run, jobs):
+            if verbose:
+                print("[hipcc] %s -> %s" % (os.path.basename(s), "ok" if rc == 0 else "FAILED"))
+            if out.strip() and (rc != 0 or verbose):
+                print(out)
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    lib = lib_path()
+    if jobs or not os.path.exists(lib) or os.path.getmtime(lib) < _newest(objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            print(r.stdout)
+            raise RuntimeError("link failed")
+        if verbose:
+            print("[link] %s" % lib)
+    return lib
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)

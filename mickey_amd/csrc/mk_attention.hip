@@ -1,0 +1,168 @@
+// mickey_amd -- flash-style multi-head attention forward for gfx950, head_dim 64, non-causal.
+// Replaces q@k^T -> softmax -> @v of reference DINO_modules/layers/attention.py:53-59 (the xformers
+// path :72-76 is the same maths).  The ntok x ntok score matrix never leaves registers.
+//
+// Design (wave64, v_mfma_f32_32x32x16):
+//  * workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 queries.
+//  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
+//    (lane-linear image; XOR swizzle on the source address + on the ds_read_b128), double-buffered.
+//  * S^T = K.Q^T ("swapped" product): after the MFMA a lane holds 32 scores of ONE query, so the
+//    row max / row sum are register-local plus one lane<->lane+32 exchange.
+//  * O^T = V^T.P^T: the P^T B-operand is exactly the registers the lane already holds (converted
+//    to 16 bit) -- no cross-lane movement -- because mk_gemm_qkv stores V^T with token bits 2<->3
+//    swapped, which makes the 8 keys a lane owns per k-step one contiguous 16-byte LDS chunk.
+//  * q arrives pre-multiplied by 64^-0.5*log2(e); softmax uses exp2.
+#include "mk_common.hpp"
+
+namespace {
+using namespace mk;
+
+constexpr int KV_TILE_BYTES = 64 * 64 * 2;  // 8 KiB
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ vt, T* __restrict__ out, int ldo, int heads,
+                                                          int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int head = blockIdx.y, img = blockIdx.z;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int j = lane & 31, hi = lane >> 5;
+
+  int qrow = q0 + j;
+  qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+  V8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+
+  const int srow = lane >> 3, sp = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * KV_TILE_BYTES;
+    char* sV = sK + KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ii = wave * 2 + t;
+      const int r = ii * 8 + srow;
+      glds16(Kh + (long long)(kt * 64 + r) * 64 + swz8(r, sp) * 8, sK + ii * 1024);
+      glds16(Vh + (long long)r * ntok_pad + kt * 64 + swz8(r, sp) * 8, sV + ii * 1024);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nkt = (ntok + 63) >> 6;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+    const char* sV = sK + KV_TILE_BYTES;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      const int row = kb * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 2 + hi) * 16);
+        s[kb] = Lp<T>::mma32(kf, qf[ks], s[kb]);
+      }
+    }
+    if (kt == nkt - 1 && (ntok & 63)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= ntok) s[kb][r] = -1e30f;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(s[kb][r] - m_new);
+        s[kb][r] = pv;
+        rs += pv;
+      }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o[0][i] *= alpha;
+      o[1][i] *= alpha;
+    }
+    V8 pf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)s[s4 >> 1][(s4 & 1) * 8 + e];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int row = dt * 32 + j;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
+        o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + j;
+  if (qi < ntok) {
+    T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        V4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][r4 * 4 + e] * inv);
+        *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads,
+                                 int ntok, int ntok_pad, int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(q && k && vt && out, "mk_flash_attn_fwd: null pointer");
+  MK_CHECK_ARG(nimg > 0 && heads > 0 && ntok > 0 && ntok_pad % 64 == 0 && ntok_pad >= ntok && ldo % 4 == 0 &&
+                   ldo >= heads * 64,
+               "mk_flash_attn_fwd: bad geometry");
+  dim3 grid((ntok + 127) / 128, heads, nimg);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)vt, (__bf16*)out, ldo, heads, ntok, ntok_pad);
+  else if (dtype == MK_F16)
+    hipLaunchKernelGGL(attn_fwd_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)q,
+                       (const _Float16*)k, (const _Float16*)vt, (_Float16*)out, ldo, heads, ntok, ntok_pad);
+  else
+    MK_CHECK_ARG(false, "mk_flash_attn_fwd: bad dtype");
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}

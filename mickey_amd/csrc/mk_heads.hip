@@ -1,0 +1,294 @@
+// mickey_amd -- small kernels of the four MicKey heads (reference mickey_extractor.py:67-251):
+// sine positional encoding add, LoFTR linear attention (att_layers/attention.py:46-64) and the head
+// tails.  None of these is FLOP-heavy (the heads' FLOPs live in mk_conv3x3 / mk_gemm_grouped);
+// they are written for few launches, coalesced 16-byte accesses and deterministic reductions.
+#include "mk_common.hpp"
+
+namespace {
+using namespace mk;
+
+constexpr int KVW = 272;     // 16x16 KV + 16 Ksum per (group, image, head)
+constexpr int KV_CHUNK = 64; // tokens per partial block
+
+template <typename T>
+__global__ __launch_bounds__(256) void posenc_kernel(const T* __restrict__ x, const float* __restrict__ pe,
+                                                     float* __restrict__ xs, T* __restrict__ cat, int ld_cat, long long rows,
+                                                     int npix, int C, long long total4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (C / 4));
+    const long long r = i / (C / 4);  // row over [G*rows)
+    const long long rr = r % rows;
+    const int pix = (int)(rr % npix);
+    const typename Lp<T>::V4 v = *(const typename Lp<T>::V4*)(x + r * C + c4 * 4);
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = (float)v[e];
+    if (pe) f += *(const f32x4*)(pe + (long long)pix * C + c4 * 4);
+    *(f32x4*)(xs + r * C + c4 * 4) = f;
+    typename Lp<T>::V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (T)f[e];
+    *(typename Lp<T>::V4*)(cat + r * ld_cat + c4 * 4) = o;
+  }
+}
+
+__device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.0f : expf(x); }  // elu(x) + 1
+
+// partial KV over a chunk of tokens: thread (d = t>>4, v = t&15)
+__global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restrict__ qkv, float* __restrict__ part, int L, int C,
+                                                          int nchunk) {
+  const int H = C >> 4;
+  const int gih = blockIdx.y;           // (g*nimg + img)*H + h
+  const int h = gih % H;
+  const long long gi = gih / H;         // g*nimg + img
+  const int chunk = blockIdx.x;
+  const int d = threadIdx.x >> 4, v = threadIdx.x & 15;
+  const int s0 = chunk * KV_CHUNK, s1 = min(L, s0 + KV_CHUNK);
+  const float invL = 1.0f / (float)L;
+  const float* base = qkv + gi * (long long)L * 3 * C;
+  float acc = 0.f, ks = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    const float* row = base + (long long)s * 3 * C;
+    const float kd = phi(row[C + h * 16 + d]);
+    const float vv = row[2 * C + h * 16 + v] * invL;
+    acc += kd * vv;
+    ks += kd;
+  }
+  float* o = part + ((long long)gih * nchunk + chunk) * KVW;
+  o[d * 16 + v] = acc;
+  if (v == 0) o[256 + d] = ks;
+}
+
+__global__ __launch_bounds__(KVW) void linattn_kv_reduce(const float* __restrict__ part, float* __restrict__ kv, int nchunk) {
+  const long long gih = blockIdx.x;
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += part[(gih * nchunk + c) * KVW + t];
+  kv[gih * KVW + t] = s;
+}
+
+// block = 32 tokens x 8... generally (256/H) tokens x H heads of one (g, img)
+template <typename T>
+__global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ kv,
+                                                            T* __restrict__ out, int ldo, int L, int C) {
+  extern __shared__ __attribute__((aligned(16))) float skv[];  // [H][273]
+  const int H = C >> 4;
+  const long long gi = blockIdx.y;
+  for (int i = threadIdx.x; i < H * KVW; i += blockDim.x) skv[(i / KVW) * 273 + (i % KVW)] = kv[gi * H * KVW + i];
+  __syncthreads();
+  const int tpb = 256 / H;
+  const int h = threadIdx.x % H;
+  const int s = blockIdx.x * tpb + threadIdx.x / H;
+  if (s >= L || threadIdx.x >= tpb * H) return;
+  const float* qrow = qkv + (gi * L + s) * 3 * C + h * 16;
+  float Q[16];
+#pragma unroll
+  for (int d4 = 0; d4 < 4; ++d4) {
+    const f32x4 t4 = *(const f32x4*)(qrow + d4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Q[d4 * 4 + e] = phi(t4[e]);
+  }
+  const float* K = skv + h * 273;
+  float z = 0.f;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) z += Q[d] * K[256 + d];
+  const float scale = (float)L / (z + 1e-6f);
+  typename Lp<T>::V8 o0, o1;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) a += Q[d] * K[d * 16 + v];
+    a *= scale;
+    if (v < 8) o0[v] = (T)a; else o1[v - 8] = (T)a;
+  }
+  T* orow = out + (gi * L + s) * ldo + h * 16;
+  *(typename Lp<T>::V8*)orow = o0;
+  *(typename Lp<T>::V8*)(orow + 8) = o1;
+}
+
+// ---- tails ---------------------------------------------------------------------------------------
+
+// detector: one workgroup per image (reference mickey_extractor.py:98-124,134-138)
+__global__ __launch_bounds__(1024) void det_tail_kernel(const float* __restrict__ feat, const float* __restrict__ wsc,
+                                                        float* __restrict__ scr, int h, int w, int C, int border,
+                                                        int use_softmax) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [n] scores + [32] reduction scratch
+  const int n = h * w;
+  float* sred = sm + n;
+  const int img = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // one wave per pixel: C-long dot product
+  for (int p = wave; p < n; p += nw) {
+    const float* f = feat + ((long long)img * n + p) * C;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += f[c] * wsc[c];
+    a = wave_sum(a);
+    if (lane == 0) sm[p] = a;
+  }
+  __syncthreads();
+  if (!use_softmax) {
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+      const int y = p / w, x = p % w;
+      const bool in = y >= border && y < h - border && x >= border && x < w - border;
+      scr[(long long)img * n + p] = in ? 1.0f / (1.0f + expf(-sm[p])) : 0.f;
+    }
+    return;
+  }
+  float a = 0.f;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) a += sm[p];
+  a = wave_sum(a);
+  if (lane == 0) sred[wave] = a;
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < nw; ++i) tot += sred[i];
+  const float mean = tot / (float)n + 1e-16f;
+  __syncthreads();
+  float es = 0.f;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const int y = p / w, x = p % w;
+    const bool in = y >= border && y < h - border && x >= border && x < w - border;
+    const float e = in ? expf((sm[p] - mean) / 100.0f) : 0.f;
+    sm[p] = e;
+    es += e;
+  }
+  es = wave_sum(es);
+  if (lane == 0) sred[wave] = es;
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = 0; i < nw; ++i) sum += sred[i];
+  const float inv = 1.0f / (sum + 1e-16f);
+  for (int p = threadIdx.x; p < n; p += blockDim.x) scr[(long long)img * n + p] = sm[p] * inv;
+}
+
+// offset + depth: one wave per pixel
+__global__ __launch_bounds__(256) void kp_depth_tail_kernel(const float* __restrict__ foff, const float* __restrict__ wxy,
+                                                            const float* __restrict__ fdep, const float* __restrict__ wd,
+                                                            float* __restrict__ kps, float* __restrict__ depth, int nimg,
+                                                            int h, int w, int C, int use_depth_sigmoid, float max_depth,
+                                                            float down) {
+  const int n = h * w;
+  const long long gp = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (gp >= (long long)nimg * n) return;
+  const int lane = threadIdx.x & 63;
+  const int img = (int)(gp / n), p = (int)(gp % n);
+  float ax = 0.f, ay = 0.f, ad = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float fo = foff[gp * C + c];
+    ax += fo * wxy[c];
+    ay += fo * wxy[C + c];
+    ad += fdep[gp * C + c] * wd[c];
+  }
+  ax = wave_sum(ax);
+  ay = wave_sum(ay);
+  ad = wave_sum(ad);
+  if (lane == 0) {
+    const int y = p / w, x = p % w;
+    kps[((long long)img * 2 + 0) * n + p] = (1.0f / (1.0f + expf(-ax)) + (float)x) * down;
+    kps[((long long)img * 2 + 1) * n + p] = (1.0f / (1.0f + expf(-ay)) + (float)y) * down;
+    depth[gp] = use_depth_sigmoid ? max_depth * (1.0f / (1.0f + expf(-ad))) : ad;
+  }
+}
+
+// descriptors: l2-normalise over channels and transpose [pix, Cd] -> [Cd, pix]; block = 64 pixels
+__global__ __launch_bounds__(256) void dsc_tail_kernel(const float* __restrict__ fdsc, float* __restrict__ dsc, int n, int Cd,
+                                                       int norm_dsc) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [Cd][65]
+  const int img = blockIdx.y, p0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int pp = wave; pp < 64; pp += 4) {
+    const int p = p0 + pp;
+    if (p >= n) break;
+    const float* f = fdsc + ((long long)img * n + p) * Cd;
+    float q = 0.f;
+    for (int c = lane; c < Cd; c += 64) q += f[c] * f[c];
+    q = wave_sum(q);
+    const float sc = norm_dsc ? 1.0f / sqrtf(q + 1e-10f) : 1.0f;
+    for (int c = lane; c < Cd; c += 64) tile[c * 65 + pp] = f[c] * sc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cd * 64; i += blockDim.x) {
+    const int c = i >> 6, pp = i & 63;
+    if (p0 + pp < n) dsc[((long long)img * Cd + c) * n + p0 + pp] = tile[c * 65 + pp];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mk_posenc_add(const void* x, const float* pe, float* xs, void* cat, int ld_cat, int groups, int nimg, int npix, int C,
+                  int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(x && xs && cat && groups > 0 && nimg > 0 && npix > 0 && C % 8 == 0 && ld_cat % 4 == 0 && ld_cat >= C,
+               "mk_posenc_add: bad args");
+  const long long rows = (long long)nimg * npix;
+  const long long total4 = (long long)groups * rows * (C / 4);
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL(posenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, pe, xs,
+                       (__bf16*)cat, ld_cat, rows, npix, C, total4);
+  else
+    hipLaunchKernelGGL(posenc_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, pe, xs,
+                       (_Float16*)cat, ld_cat, rows, npix, C, total4);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+long long mk_linattn_work_floats(int groups, int nimg, int L, int C) {
+  const int nchunk = (L + KV_CHUNK - 1) / KV_CHUNK;
+  return (long long)groups * nimg * (C / 16) * nchunk * KVW;
+}
+
+int mk_linattn_kv(const float* qkv, float* kv, float* work, int groups, int nimg, int L, int C, mk_stream_t stream) {
+  MK_CHECK_ARG(qkv && kv && work && groups > 0 && nimg > 0 && L > 0 && C % 16 == 0, "mk_linattn_kv: bad args");
+  const int nchunk = (L + KV_CHUNK - 1) / KV_CHUNK;
+  const int gih = groups * nimg * (C / 16);
+  hipLaunchKernelGGL(linattn_kv_partial, dim3(nchunk, gih), dim3(256), 0, (hipStream_t)stream, qkv, work, L, C, nchunk);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(linattn_kv_reduce, dim3(gih), dim3(KVW), 0, (hipStream_t)stream, work, kv, nchunk);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_linattn_apply(const float* qkv, const float* kv, void* out, int ldo, int groups, int nimg, int L, int C, int dtype,
+                     mk_stream_t stream) {
+  const int H = C / 16;
+  MK_CHECK_ARG(qkv && kv && out && groups > 0 && nimg > 0 && L > 0 && C % 16 == 0 && H <= 64 && ldo % 8 == 0 && ldo >= C,
+               "mk_linattn_apply: bad args");
+  const int tpb = 256 / H;
+  dim3 grid((L + tpb - 1) / tpb, groups * nimg);
+  const size_t lds = (size_t)H * 273 * sizeof(float);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL(linattn_apply_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (__bf16*)out, ldo, L,
+                       C);
+  else
+    hipLaunchKernelGGL(linattn_apply_kernel<_Float16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (_Float16*)out,
+                       ldo, L, C);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_head_tails(const float* feat_det, const float* w_score, const float* feat_off, const float* w_xy,
+                  const float* feat_depth, const float* w_depth, const float* feat_dsc, float* scr, float* kps, float* depth,
+                  float* dsc, int nimg, int h, int w, int C, int Cd, int border, int use_softmax, int use_depth_sigmoid,
+                  float max_depth, int norm_dsc, float down, mk_stream_t stream) {
+  MK_CHECK_ARG(feat_det && w_score && feat_off && w_xy && feat_depth && w_depth && feat_dsc && scr && kps && depth && dsc,
+               "mk_head_tails: null pointer");
+  const int n = h * w;
+  MK_CHECK_ARG(nimg > 0 && n > 0 && C > 0 && Cd > 0 && (size_t)(n + 32) * 4 <= 160 * 1024 && Cd * 65 * 4 <= 160 * 1024,
+               "mk_head_tails: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_tail_kernel, dim3(nimg), dim3(1024), (size_t)(n + 32) * sizeof(float), st, feat_det, w_score, scr, h,
+                     w, C, border, use_softmax);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(kp_depth_tail_kernel, dim3((unsigned)(((long long)nimg * n + 3) / 4)), dim3(256), 0, st, feat_off, w_xy,
+                     feat_depth, w_depth, kps, depth, nimg, h, w, C, use_depth_sigmoid, max_depth, down);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dsc_tail_kernel, dim3((n + 63) / 64, nimg), dim3(256), (size_t)Cd * 65 * sizeof(float), st, feat_dsc, dsc,
+                     n, Cd, norm_dsc);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+}  // extern "C"

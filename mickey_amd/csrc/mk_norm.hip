@@ -1,0 +1,170 @@
+// mickey_amd -- row-wise kernels of the encoder: LayerNorm, patch im2col, CLS row.  All HBM-bound:
+// one wave per row, 16-byte loads/stores, wave64 shuffle reductions, values held in registers
+// between the statistics and the normalisation (single read of x).
+#include "mk_common.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace {
+using namespace mk;
+
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, void* out, int ldo,
+                                                        int out_is_f32, float* resid, int ldr, int rows_out, int D,
+                                                        int rows_per_img, int skip) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_out) return;
+  const int rpo = rows_per_img - skip;
+  const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
+  const float* xr = x + rin * ldx;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      v[i] = *(const f32x4*)(xr + c);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const f32x4 ww = *(const f32x4*)(w + c), bb = *(const f32x4*)(b + c);
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+      if (resid) {
+        float* rp = resid + (long long)r * ldr + c;
+        y += *(const f32x4*)rp;
+        *(f32x4*)rp = y;
+      }
+      if (out) {
+        if (out_is_f32) {
+          *(f32x4*)((float*)out + (long long)r * ldo + c) = y;
+        } else {
+          typename Lp<T>::V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
+          *(typename Lp<T>::V4*)((T*)out + (long long)r * ldo + c) = o;
+        }
+      }
+    }
+  }
+}
+
+// one thread per 4 output columns (k = ch*196 + dy*14 + dx); rows = patches
+template <typename T>
+__global__ __launch_bounds__(256) void im2col14_kernel(const float* __restrict__ img, long long stride_img,
+                                                       long long stride_ch, int stride_row, int nimg, int gh, int gw,
+                                                       T* __restrict__ out, int ldo) {
+  const int cols4 = ldo >> 2;
+  const long long total = (long long)nimg * gh * gw * cols4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cols4);
+    const long long m = i / cols4;
+    const int pc = (int)(m % gw);
+    const int pr = (int)((m / gw) % gh);
+    const int im = (int)(m / ((long long)gw * gh));
+    typename Lp<T>::V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = c4 * 4 + e;
+      float v = 0.f;
+      if (k < 588) {
+        const int ch = k / 196, rem = k - ch * 196, dy = rem / 14, dx = rem - dy * 14;
+        v = img[im * stride_img + ch * stride_ch + (long long)(pr * 14 + dy) * stride_row + pc * 14 + dx];
+      }
+      o[e] = (T)v;
+    }
+    *(typename Lp<T>::V4*)(out + m * ldo + c4 * 4) = o;
+  }
+}
+
+__global__ void cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x, int nimg,
+                           int ntok, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * D) return;
+  const int im = i / D, c = i - im * D;
+  x[(long long)im * ntok * D + c] = cls[c] + pos[c];
+}
+
+}  // namespace
+
+// ---- error string + version (host side) ---------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void mk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int mk_version(void) { return 100; }
+const char* mk_last_error(void) { return g_err; }
+
+int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(x && w && b && (out || resid), "mk_layernorm: null pointer");
+  MK_CHECK_ARG(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, "mk_layernorm: D=%d must be a multiple of 4 and <= %d", D,
+               LN_MAXV * 256);
+  MK_CHECK_ARG(rows_out > 0 && rows_per_img > skip && skip >= 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
+               "mk_layernorm: bad geometry");
+  dim3 grid((rows_out + 3) / 4);
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
+                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
+                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_im2col_patch14(const float* img, long long stride_img, long long stride_ch, int stride_row, int nimg, int gh,
+                      int gw, void* out, int ldo, int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(img && out && nimg > 0 && gh > 0 && gw > 0, "mk_im2col_patch14: bad args");
+  MK_CHECK_ARG(ldo >= 588 && ldo % 8 == 0, "mk_im2col_patch14: ldo=%d must be >= 588 and a multiple of 8", ldo);
+  const long long total = (long long)nimg * gh * gw * (ldo / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL(im2col14_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, stride_img, stride_ch,
+                       stride_row, nimg, gh, gw, (__bf16*)out, ldo);
+  else
+    hipLaunchKernelGGL(im2col14_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, stride_img,
+                       stride_ch, stride_row, nimg, gh, gw, (_Float16*)out, ldo);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int ntok, int D, mk_stream_t stream) {
+  MK_CHECK_ARG(cls && pos && x && nimg > 0 && ntok > 0 && D > 0, "mk_cls_token: bad args");
+  hipLaunchKernelGGL(cls_kernel, dim3((nimg * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos, x, nimg, ntok, D);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+}  // extern "C"

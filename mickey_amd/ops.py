@@ -1,0 +1,232 @@
+"""Tensor-level wrappers over the C ABI (include/mickey_hip.h).  Each function allocates its outputs
+with torch (device memory only), passes raw pointers + the current HIP stream to libmickey_hip.so and
+returns tensors.  No arithmetic happens here."""
+import math
+
+import torch
+
+from . import _native as nv
+from ._native import ACT_GELU, ACT_NONE, ACT_RELU, call, dtype_code, ptr, query, stream  # noqa: F401
+
+LOG2E = 1.4426950408889634
+
+
+def _chk(t, dtype=None):
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+    if dtype is not None:
+        assert t.dtype == dtype, "expected %s, got %s" % (dtype, t.dtype)
+    return t
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, out_f32=False, out=None, lda=None, K=None):
+    """out = act(a[:, :K] @ w[:, :K].T + bias).  a [M, lda] lp, w [N, ldw] lp."""
+    M = a.shape[0]
+    lda = a.shape[1] if lda is None else lda
+    N, ldw = w.shape
+    K = min(lda, ldw) if K is None else K
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    call("mk_gemm", ptr(a), lda, ptr(w), ldw, ptr(bias), ptr(out), out.stride(0), M, N, K, act, int(out_f32),
+         dtype_code(a.dtype), stream())
+    return out
+
+
+def gemm_grouped(a, w, bias, out, groups, M, N, K, lda, ldw, ldc, stride_a, stride_w, stride_bias, stride_out, act=ACT_NONE):
+    call("mk_gemm_grouped", ptr(a), lda, stride_a, ptr(w), ldw, stride_w, ptr(bias), stride_bias, ptr(out), ldc, stride_out,
+         groups, M, N, K, act, int(out.dtype == torch.float32), dtype_code(a.dtype), stream())
+    return out
+
+
+def gemm_ls_residual(a, w, bias, gamma, x):
+    """x += gamma * (a @ w.T + bias), x fp32 [M, N] in place."""
+    M, K = a.shape
+    N = w.shape[0]
+    call("mk_gemm_ls_residual", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(x), x.stride(0), M, N, K,
+         dtype_code(a.dtype), stream())
+    return x
+
+
+def gemm_qkv(a, w, bias, q, k, vt, nimg, ntok, ntok_pad, heads):
+    qscale = (64.0 ** -0.5) * LOG2E
+    call("mk_gemm_qkv", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(q), ptr(k), ptr(vt), nimg, ntok, ntok_pad,
+         heads, qscale, dtype_code(a.dtype), stream())
+
+
+def im2col_patch14(img, gh, gw, ldo, dtype):
+    """img fp32 [nimg, 3, H, W] (any strides with unit innermost) -> [nimg*gh*gw, ldo] lp."""
+    assert img.dtype == torch.float32 and img.stride(3) == 1
+    nimg = img.shape[0]
+    out = torch.empty((nimg * gh * gw, ldo), device=img.device, dtype=dtype)
+    call("mk_im2col_patch14", ptr(img), img.stride(0), img.stride(1), img.stride(2), nimg, gh, gw, ptr(out), ldo,
+         dtype_code(dtype), stream())
+    return out
+
+
+def gemm_patch_embed(a, w, bias, pos, x, nimg, npatch):
+    D = w.shape[0]
+    call("mk_gemm_patch_embed", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(pos), ptr(x), nimg, npatch, D,
+         w.shape[1], dtype_code(a.dtype), stream())
+
+
+def cls_token(cls, pos, x, nimg, ntok, D):
+    call("mk_cls_token", ptr(cls), ptr(pos), ptr(x), nimg, ntok, D, stream())
+
+
+def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows_out=None, rows_per_img=None, skip=0,
+              ldo=None):
+    """LayerNorm rows of fp32 x [rows, D]; see mk_layernorm for the row remap and the residual form."""
+    D = w.shape[0]
+    rows_in = x.shape[0]
+    if rows_per_img is None:
+        rows_per_img = rows_in
+    if rows_out is None:
+        rows_out = rows_in - skip * (rows_in // rows_per_img)
+    if out is None and out_dtype is not None:
+        out = torch.empty((rows_out, D), device=x.device, dtype=out_dtype)
+    is_f32 = out is not None and out.dtype == torch.float32
+    ldo = (out.stride(0) if out is not None else D) if ldo is None else ldo
+    lp = out.dtype if (out is not None and not is_f32) else torch.bfloat16
+    call("mk_layernorm", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(out), ldo, int(is_f32), ptr(resid),
+         resid.stride(0) if resid is not None else D, rows_out, D, rows_per_img, skip, dtype_code(lp), stream())
+    return out
+
+
+def flash_attn(q, k, vt, out, nimg, heads, ntok, ntok_pad):
+    call("mk_flash_attn_fwd", ptr(q), ptr(k), ptr(vt), ptr(out), out.stride(0), nimg, heads, ntok, ntok_pad,
+         dtype_code(q.dtype), stream())
+    return out
+
+
+def conv3x3(in1, C1, w, bias, out, Cout, groups, nimg, H, W, zero_page, act=ACT_NONE, in2=None, C2=0, resid=None,
+            stride_in1=0, stride_in2=0, stride_w=0, stride_bias=0, stride_out=0):
+    call("mk_conv3x3", ptr(in1), stride_in1, C1, ptr(in2), stride_in2, C2, ptr(w), w.shape[-1], stride_w, ptr(bias), stride_bias,
+         ptr(resid), ptr(out), Cout, stride_out, groups, nimg, H, W, act, int(out.dtype == torch.float32), ptr(zero_page),
+         dtype_code(in1.dtype), stream())
+    return out
+
+
+def posenc_add(x, pe, xs, cat, groups, nimg, npix, C):
+    call("mk_posenc_add", ptr(x), ptr(pe), ptr(xs), ptr(cat), cat.stride(-2), groups, nimg, npix, C, dtype_code(x.dtype),
+         stream())
+
+
+def linattn_work_floats(groups, nimg, L, C):
+    return query("mk_linattn_work_floats", groups, nimg, L, C)
+
+
+def linattn_kv(qkv, kv, work, groups, nimg, L, C):
+    call("mk_linattn_kv", ptr(qkv), ptr(kv), ptr(work), groups, nimg, L, C, stream())
+
+
+def linattn_apply(qkv, kv, out, ldo, groups, nimg, L, C):
+    call("mk_linattn_apply", ptr(qkv), ptr(kv), ptr(out), ldo, groups, nimg, L, C, dtype_code(out.dtype), stream())
+
+
+def head_tails(f_det, w_score, f_off, w_xy, f_dep, w_dep, f_dsc, nimg, h, w, C, Cd, border=3, use_softmax=True,
+               use_depth_sigmoid=False, max_depth=60.0, norm_dsc=True, down=14.0):
+    dev = f_det.device
+    n = h * w
+    scr = torch.empty((nimg, 1, n), device=dev, dtype=torch.float32)
+    kps = torch.empty((nimg, 2, n), device=dev, dtype=torch.float32)
+    depth = torch.empty((nimg, 1, n), device=dev, dtype=torch.float32)
+    dsc = torch.empty((nimg, Cd, n), device=dev, dtype=torch.float32)
+    call("mk_head_tails", ptr(f_det), ptr(w_score), ptr(f_off), ptr(w_xy), ptr(f_dep), ptr(w_dep), ptr(f_dsc), ptr(scr),
+         ptr(kps), ptr(depth), ptr(dsc), nimg, h, w, C, Cd, border, int(use_softmax), int(use_depth_sigmoid), float(max_depth),
+         int(norm_dsc), float(down), stream())
+    return scr, kps, depth, dsc
+
+
+def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None, want_scores=True, want_kp=True,
+                 want_final=True):
+    """Returns (scores, kp_scores, final_scores) (None where not requested)."""
+    _chk(dsc0, torch.float32)
+    _chk(dsc1, torch.float32)
+    B, C, n0 = dsc0.shape
+    n1 = dsc1.shape[2]
+    dev = dsc0.device
+    mk = lambda want: torch.empty((B, n0, n1), device=dev, dtype=torch.float32) if want else None  # noqa: E731
+    scores = mk(want_scores)
+    kp = mk(want_kp and scr0 is not None)
+    fin = mk(want_final and scr0 is not None)
+    work = torch.empty((query("mk_dual_softmax_work_floats", B, n0, n1),), device=dev, dtype=torch.float32)
+    call("mk_dual_softmax", ptr(dsc0), ptr(dsc1), ptr(scr0), ptr(scr1), 1.0 / float(temperature), int(dustbin is not None),
+         float(dustbin) if dustbin is not None else 0.0, ptr(scores), ptr(kp), ptr(fin), ptr(work), B, C, n0, n1, stream())
+    return scores, kp, fin
+
+
+def sinkhorn(dsc0, dsc1, alpha, iters=10):
+    B, C, n0 = dsc0.shape
+    n1 = dsc1.shape[2]
+    out = torch.empty((B, n0, n1), device=dsc0.device, dtype=torch.float32)
+    work = torch.empty((query("mk_sinkhorn_work_floats", B, n0, n1),), device=dsc0.device, dtype=torch.float32)
+    call("mk_sinkhorn", ptr(dsc0), ptr(dsc1), float(alpha), int(iters), ptr(out), ptr(work), B, C, n0, n1, stream())
+    return out
+
+
+def mutual_nn(scores):
+    """Batched get_matches_list: returns (matches int32 [B, n0, 2], count int32 [B])."""
+    _chk(scores, torch.float32)
+    B, n0, n1 = scores.shape
+    dev = scores.device
+    matches = torch.zeros((B, n0, 2), device=dev, dtype=torch.int32)
+    count = torch.zeros((B,), device=dev, dtype=torch.int32)
+    work = torch.empty((2 * B * (n0 + n1),), device=dev, dtype=torch.int32)
+    call("mk_mutual_nn", ptr(scores), ptr(matches), ptr(count), ptr(work), B, n0, n1, stream())
+    return matches, count
+
+
+# ---- solver ---------------------------------------------------------------------------------------
+
+def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0):
+    """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
+    _chk(p, torch.float32)
+    B, ncell = p.shape
+    dev = p.device
+    idx = torch.empty((B * rows_per_pair, k), device=dev, dtype=torch.int32)
+    cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
+    work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k),), device=dev, dtype=torch.uint8)
+    call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(idx), ptr(cnt), ptr(work), B, rows_per_pair,
+         ncell, k, stream())
+    return idx, cnt
+
+
+def gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, rows_per_pair):
+    B, n0, n1 = final_scores.shape
+    R, k = idx.shape
+    dev = idx.device
+    X = torch.empty((R, k, 3), device=dev, dtype=torch.float32)
+    Y = torch.empty((R, k, 3), device=dev, dtype=torch.float32)
+    wts = torch.empty((R, k), device=dev, dtype=torch.float32)
+    corr = torch.empty((R, k, 6), device=dev, dtype=torch.float32)
+    call("mk_gather_backproject", ptr(idx), ptr(final_scores), ptr(kps0), ptr(depth0), ptr(kps1), ptr(depth1), ptr(K0),
+         ptr(K1), ptr(X), ptr(Y), ptr(wts), ptr(corr), B, rows_per_pair, k, n0, n1, stream())
+    return X, Y, wts, corr
+
+
+def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0):
+    nsets, k, _ = X.shape
+    dev = X.device
+    nh = nsets * it_ransac
+    Rh = torch.empty((nh, 9), device=dev, dtype=torch.float32)
+    th = torch.empty((nh, 3), device=dev, dtype=torch.float32)
+    score = torch.empty((nh,), device=dev, dtype=torch.float32)
+    idx3 = torch.empty((nh, 3), device=dev, dtype=torch.int32)
+    call("mk_ransac_hypotheses", ptr(X), ptr(Y), ptr(wts), ptr(noise3), ptr(idx3_in), int(seed), int(offset), float(th_soft),
+         ptr(Rh), ptr(th), ptr(score), ptr(idx3), nsets, it_ransac, k, stream())
+    return Rh, th, score, idx3
+
+
+def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers):
+    k = X.shape[1]
+    dev = X.device
+    R = torch.empty((B, 3, 3), device=dev, dtype=torch.float32)
+    t = torch.empty((B, 1, 3), device=dev, dtype=torch.float32)
+    conf = torch.empty((B, 1), device=dev, dtype=torch.float32)
+    best = torch.empty((B,), device=dev, dtype=torch.int32)
+    mask = torch.empty((B, k), device=dev, dtype=torch.uint8)
+    rounds = torch.empty((B,), device=dev, dtype=torch.int32)
+    invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
+    call("mk_refine_pose", ptr(X), ptr(Y), ptr(Rh), ptr(th), ptr(score), float(th_inlier), int(num_ref), int(min_inliers),
+         ptr(R), ptr(t), ptr(conf), ptr(best), ptr(mask), ptr(rounds), ptr(invalid), B, it_matches, it_ransac, k, stream())
+    call("mk_pose_finalize", ptr(R), ptr(t), ptr(conf), ptr(invalid), B, stream())
+    return R, t, conf, best, mask, rounds, invalid

@@ -1,0 +1,295 @@
+"""-m gpu: each HIP kernel, called through the C ABI, against a plain fp32 torch reference of the same
+op computed on the SAME (already 16-bit-rounded) inputs -- so the only differences are accumulation
+order and the output rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64)])
+def test_gemm_bias_act(dtype, M, N, K):
+    from mickey_amd import ops
+    dev = _dev()
+    a = (torch.randn((M, K), generator=g(1)) * 0.5).to(dtype)
+    w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).to(dtype)
+    bias = torch.randn((N,), generator=g(3))
+    ref = a.float() @ w.float().t() + bias
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_RELU, F.relu), (ops.ACT_GELU, F.gelu)):
+        out32 = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), act=act, out_f32=True)
+        assert rel(out32, fn(ref)) < 2e-5, (act, rel(out32, fn(ref)))
+        outlp = ops.gemm(a.to(dev), w.to(dev), bias.to(dev), act=act, out_f32=False)
+        assert outlp.dtype == dtype
+        assert rel(outlp.float(), fn(ref)) < (5e-3 if dtype == torch.bfloat16 else 8e-4)
+    # asymmetric-operand transpose check: A = identity block picks rows of W
+    eye = torch.zeros((64, K), dtype=dtype)
+    eye[torch.arange(64), torch.arange(64)] = 1.0
+    out = ops.gemm(eye.to(dev), w.to(dev), None, out_f32=True)
+    assert torch.equal(out.cpu(), w.float()[:, :64].t().contiguous())
+
+
+def test_gemm_ls_residual():
+    from mickey_amd import ops
+    dev = _dev()
+    M, N, K = 3878, 1024, 4096
+    a = (torch.randn((M, K), generator=g(1)) * 0.5).bfloat16()
+    w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).bfloat16()
+    bias, gamma = torch.randn((N,), generator=g(3)), torch.rand((N,), generator=g(4))
+    x = torch.randn((M, N), generator=g(5))
+    ref = x + gamma * (a.float() @ w.float().t() + bias)
+    xd = x.to(dev)
+    ops.gemm_ls_residual(a.to(dev), w.to(dev), bias.to(dev), gamma.to(dev), xd)
+    assert rel(xd, ref) < 1e-5
+
+
+def test_gemm_qkv_layout():
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, ntok, heads = 2, 333, 4
+    D, pad = heads * 64, 384
+    a = (torch.randn((nimg * ntok, D), generator=g(1)) * 0.5).bfloat16()
+    w = (torch.randn((3 * D, D), generator=g(2)) / math.sqrt(D)).bfloat16()
+    bias = torch.randn((3 * D,), generator=g(3))
+    q = torch.zeros((nimg, heads, pad, 64), device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((nimg, heads, 64, pad), device=dev, dtype=torch.bfloat16)
+    ops.gemm_qkv(a.to(dev), w.to(dev), bias.to(dev), q, k, vt, nimg, ntok, pad, heads)
+    ref = (a.float() @ w.float().t() + bias).reshape(nimg, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    qs = (64.0 ** -0.5) * ops.LOG2E
+    assert rel(q[:, :, :ntok].float(), ref[0] * qs) < 5e-3
+    assert rel(k[:, :, :ntok].float(), ref[1]) < 5e-3
+    t = torch.arange(pad)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    v_unperm = vt.cpu().float()[:, :, :, perm]  # position perm(t) holds token t
+    assert rel(v_unperm[..., :ntok], ref[2].transpose(-1, -2)) < 5e-3
+    assert float(q[:, :, ntok:].abs().sum()) == 0.0  # pad rows untouched
+
+
+def test_patch_embed_and_cls():
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, H, W, D = 2, 75, 101, 256   # cropped to 70 x 98 -> 5 x 7 patches
+    gh, gw = H // 14, W // 14
+    img = torch.rand((nimg, 3, H, W), generator=g(1))
+    wconv = torch.randn((D, 3, 14, 14), generator=g(2)) / math.sqrt(588)
+    bias = torch.randn((D,), generator=g(3)) * 0.1
+    pos = torch.randn((1 + gh * gw, D), generator=g(4)) * 0.1
+    cls = torch.randn((D,), generator=g(5)) * 0.1
+    a = ops.im2col_patch14(img.to(dev), gh, gw, 640, torch.bfloat16)
+    w2 = torch.zeros((D, 640))
+    w2[:, :588] = wconv.reshape(D, 588)
+    x = torch.zeros((nimg, 1 + gh * gw, D), device=dev)
+    ops.gemm_patch_embed(a, w2.bfloat16().to(dev), bias.to(dev), pos.to(dev), x, nimg, gh * gw)
+    ops.cls_token(cls.to(dev), pos.to(dev), x, nimg, 1 + gh * gw, D)
+    crop = img[:, :, : gh * 14, : gw * 14].bfloat16().float()
+    ref = F.conv2d(crop, wconv.bfloat16().float(), bias, stride=14).flatten(2).transpose(1, 2) + pos[1:]
+    assert rel(x[:, 1:], ref) < 1e-5
+    assert rel(x[:, 0], (cls + pos[0]).expand(nimg, D)) < 1e-7
+
+
+@pytest.mark.parametrize("D", [128, 384, 1024])
+def test_layernorm(D):
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, ntok = 3, 50
+    x = torch.randn((nimg * ntok, D), generator=g(1)) * 3 + 0.5
+    w, b = torch.randn((D,), generator=g(2)), torch.randn((D,), generator=g(3))
+    ref = F.layer_norm(x, (D,), w, b, 1e-6)
+    out = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, out_dtype=torch.float32)
+    assert rel(out, ref) < 2e-6
+    out16 = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, out_dtype=torch.bfloat16)
+    assert rel(out16.float(), ref) < 4e-3
+    # drop the first row of every image (CLS)
+    outs = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, out_dtype=torch.float32, rows_per_img=ntok, skip=1)
+    assert rel(outs, ref.reshape(nimg, ntok, D)[:, 1:].reshape(-1, D)) < 2e-6
+    # residual form
+    r = torch.randn((nimg * ntok, D), generator=g(4))
+    rd = r.to(dev)
+    o2 = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-5, out_dtype=torch.bfloat16, resid=rd)
+    ref2 = r + F.layer_norm(x, (D,), w, b, 1e-5)
+    assert rel(rd, ref2) < 2e-6 and rel(o2.float(), ref2) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ntok", [64, 200, 1939])
+def test_flash_attention(dtype, ntok):
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, heads = 2, 3
+    D = heads * 64
+    pad = (ntok + 63) // 64 * 64
+    qkv = torch.randn((3, nimg, heads, ntok, 64), generator=g(ntok)) * 1.5
+    qkv[0, 0, 0, 5] *= 6.0   # a spiky query row: forces large running-max jumps
+    qkv[1, 0, 0, 130 % ntok] *= 6.0
+    q16, k16, v16 = (qkv[0] * 0.125 * ops.LOG2E).to(dtype), qkv[1].to(dtype), qkv[2].to(dtype)
+    q = torch.zeros((nimg, heads, pad, 64), dtype=dtype)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((nimg, heads, 64, pad), dtype=dtype)
+    q[:, :, :ntok], k[:, :, :ntok] = q16, k16
+    t = torch.arange(ntok)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    vt[:, :, :, perm] = v16.transpose(-1, -2)
+    out = torch.zeros((nimg * ntok, D), device=dev, dtype=dtype)
+    ops.flash_attn(q.to(dev), k.to(dev), vt.to(dev), out, nimg, heads, ntok, pad)
+    s = (q16.double() @ k16.double().transpose(-1, -2)) / ops.LOG2E
+    ref = (torch.softmax(s, -1) @ v16.double()).permute(0, 2, 1, 3).reshape(nimg * ntok, D)
+    err = rel(out.float(), ref)
+    assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
+
+
+@pytest.mark.parametrize("with_sc,with_res", [(False, False), (True, False), (False, True)])
+def test_conv3x3(with_sc, with_res):
+    from mickey_amd import ops
+    dev = _dev()
+    G, nimg, H, W, C1, C2, Cout = 3, 2, 9, 7, 128, 64, 128 if with_res else 192
+    if with_res:
+        Cout = C1
+    x = torch.randn((G, nimg, H, W, C1), generator=g(1)).bfloat16()
+    x2 = torch.randn((nimg, H, W, C2), generator=g(2)).bfloat16()
+    wc = (torch.randn((G, Cout, C1, 3, 3), generator=g(3)) / math.sqrt(9 * C1)).bfloat16()
+    ws = (torch.randn((G, Cout, C2), generator=g(4)) / math.sqrt(C2)).bfloat16()
+    bias = torch.randn((G, Cout), generator=g(5))
+    K = 9 * C1 + (C2 if with_sc else 0)
+    w2d = torch.zeros((G, Cout, K), dtype=torch.bfloat16)
+    w2d[:, :, : 9 * C1] = wc.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9 * C1)
+    if with_sc:
+        w2d[:, :, 9 * C1:] = ws
+    zero = torch.zeros(256, device=dev, dtype=torch.uint8)
+    out = torch.empty((G, nimg * H * W, Cout), device=dev, dtype=torch.float32)
+    xd = x.to(dev)
+    ops.conv3x3(xd, C1, w2d.to(dev), bias.to(dev), out, Cout, G, nimg, H, W, zero, act=ops.ACT_RELU,
+                in2=x2.to(dev) if with_sc else None, C2=C2, resid=xd if with_res else None,
+                stride_in1=nimg * H * W * C1, stride_in2=0, stride_w=Cout * K, stride_bias=Cout,
+                stride_out=nimg * H * W * Cout)
+    for gi in range(G):
+        ref = F.conv2d(x[gi].float().permute(0, 3, 1, 2), wc[gi].float(), padding=1) + bias[gi].view(1, -1, 1, 1)
+        if with_sc:
+            ref = ref + F.conv2d(x2.float().permute(0, 3, 1, 2), ws[gi].float()[:, :, None, None])
+        if with_res:
+            ref = ref + x[gi].float().permute(0, 3, 1, 2)
+        ref = F.relu(ref).permute(0, 2, 3, 1).reshape(-1, Cout)
+        assert rel(out[gi], ref) < 2e-5, (gi, rel(out[gi], ref))
+
+
+def test_grouped_gemm():
+    from mickey_amd import ops
+    dev = _dev()
+    G, M, N, K = 4, 500, 384, 128
+    a = torch.randn((G, M, 256), generator=g(1)).bfloat16()   # lda 256 > K
+    w = (torch.randn((G, N, K), generator=g(2)) / math.sqrt(K)).bfloat16()
+    out = torch.empty((G, M, N), device=dev, dtype=torch.float32)
+    ops.gemm_grouped(a.to(dev), w.to(dev), None, out, G, M, N, K, 256, K, N, M * 256, N * K, 0, M * N)
+    ref = torch.einsum("gmk,gnk->gmn", a[:, :, :K].float(), w.float())
+    assert rel(out, ref) < 2e-5
+
+
+def test_linear_attention_and_posenc():
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    G, nimg, h, w, C = 2, 2, 9, 7, 128
+    L = h * w
+    qkv = torch.randn((G, nimg * L, 3 * C), generator=g(1))
+    qd = qkv.to(dev)
+    kv = torch.empty((G * nimg * (C // 16), 272), device=dev)
+    work = torch.empty((ops.linattn_work_floats(G, nimg, L, C),), device=dev)
+    ops.linattn_kv(qd, kv, work, G, nimg, L, C)
+    out = torch.empty((G, nimg * L, C), device=dev, dtype=torch.bfloat16)
+    ops.linattn_apply(qd, kv, out, C, G, nimg, L, C)
+    x = qkv.reshape(G * nimg, L, 3, 8, 16)
+    ref = O.linear_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2]).reshape(G, nimg * L, C)
+    assert rel(out.float(), ref) < 4e-3
+    # positional encoding add
+    xin = torch.randn((G, nimg * L, C), generator=g(2)).bfloat16()
+    pe = O.sine_pos_encoding(C, h, w).reshape(C, L).t().contiguous()
+    xs = torch.empty((G, nimg * L, C), device=dev)
+    cat = torch.zeros((G, nimg * L, 2 * C), device=dev, dtype=torch.bfloat16)
+    ops.posenc_add(xin.to(dev), pe.to(dev), xs, cat, G, nimg, L, C)
+    refx = xin.float() + pe.repeat(nimg, 1)[None]
+    assert rel(xs, refx) < 1e-6 and rel(cat[:, :, :C].float(), refx) < 4e-3
+
+
+def test_head_tails():
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    nimg, h, w, C, Cd = 2, 11, 9, 64, 128
+    n = h * w
+    fd, fo, fz = (torch.randn((nimg * n, C), generator=g(i)) for i in (1, 2, 3))
+    fdsc = torch.randn((nimg * n, Cd), generator=g(4))
+    ws, wxy, wd = torch.randn((C,), generator=g(5)) * 4, torch.randn((2, C), generator=g(6)) * 0.3, torch.randn((C,), generator=g(7))
+    scr, kps, depth, dsc = ops.head_tails(fd.to(dev), ws.to(dev), fo.to(dev), wxy.to(dev), fz.to(dev), wd.to(dev), fdsc.to(dev),
+                                          nimg, h, w, C, Cd)
+    def nchw(f, c):
+        return f.reshape(nimg, h, w, c).permute(0, 3, 1, 2)
+    s_ref = O.border_softmax(F.conv2d(nchw(fd, C), ws.view(1, C, 1, 1)), 3).reshape(nimg, 1, n)
+    k_ref = O.abs_keypoints(torch.sigmoid(F.conv2d(nchw(fo, C), wxy.view(2, C, 1, 1))), 14).reshape(nimg, 2, n)
+    d_ref = F.conv2d(nchw(fz, C), wd.view(1, C, 1, 1)).reshape(nimg, 1, n)
+    x = nchw(fdsc, Cd)
+    ds_ref = (x / x.pow(2).sum(1, keepdim=True).add(1e-10).pow(0.5)).reshape(nimg, Cd, n)
+    assert rel(scr, s_ref) < 1e-5 and rel(kps, k_ref) < 1e-6 and rel(depth, d_ref) < 1e-5 and rel(dsc, ds_ref) < 1e-6
+    assert abs(float(scr.sum()) - nimg) < 1e-4
+
+
+@pytest.mark.parametrize("n0,n1", [(150, 131), (1938, 1938)])
+def test_dual_softmax_vs_oracle(n0, n1):
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    B = 2
+    d0 = F.normalize(torch.randn((B, 128, n0), generator=g(21)), dim=1)
+    d1 = F.normalize(torch.randn((B, 128, n1), generator=g(22)) + 0.5 * d0[:, :, :n1] if n1 <= n0 else
+                     torch.randn((B, 128, n1), generator=g(22)), dim=1)
+    s0 = torch.rand((B, 1, n0), generator=g(23)) / n0
+    s1 = torch.rand((B, 1, n1), generator=g(24)) / n1
+    ref = O.dual_softmax(d0, d1, 0.7, 0.1)
+    kp_ref = torch.matmul(s0.transpose(2, 1), s1)
+    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.7)
+    assert rel(sc, ref) < 1e-5, rel(sc, ref)
+    assert torch.equal(kp.cpu(), kp_ref)
+    assert rel(fin, ref * kp_ref) < 1e-5
+    # row arg-max indices identical wherever the oracle's own top-2 gap is not a tie
+    top2 = ref.topk(2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-5 * top2[..., 0]
+    assert torch.equal(sc.cpu().argmax(2)[clear], ref.argmax(2)[clear])
+    # no dustbin
+    sc2, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, None, want_kp=False, want_final=False)
+    assert rel(sc2, O.dual_softmax(d0, d1, None, 0.1)) < 1e-5
+
+
+def test_matcher_golden(golden):
+    """HIP matcher against the REFERENCE's own outputs (tests/golden/matcher.npz)."""
+    from mickey_amd import ops
+    dev = _dev()
+    gd = golden("matcher")
+    gen = g(21)
+    d0 = F.normalize(torch.randn((2, 128, 150), generator=gen), dim=1)
+    d1 = F.normalize(torch.randn((2, 128, 131), generator=gen) + 0.5 * d0[:, :, :131], dim=1)
+    sc, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, 0.7, want_kp=False, want_final=False)
+    assert rel(sc, torch.from_numpy(gd["dual_softmax"])) < 1e-5
+    sk = ops.sinkhorn(d0.to(dev), d1.to(dev), 1.3, 10)
+    assert rel(sk, torch.from_numpy(gd["sinkhorn"])) < 2e-5
+    # mutual-NN: bit-exact indices given identical scores
+    m, c = ops.mutual_nn(torch.from_numpy(gd["dual_softmax"])[:1].contiguous().to(dev))
+    cnt = int(c[0])
+    assert cnt == gd["mnn"].shape[0]
+    assert torch.equal(m[0, :cnt].cpu().long(), torch.from_numpy(gd["mnn"]))
