@@ -83,9 +83,11 @@ int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int nto
  * x fp32 [*, ldx]; output row r reads input row (r / (rows_per_img - skip)) * rows_per_img + skip +
  * r % (rows_per_img - skip)  (skip = 1 drops the CLS token, dinov2.py:233).  out lp or fp32.
  * If resid != NULL (fp32 [rows_out, ldr]): resid += LN(x) and `out` receives the updated resid
- * (transformer_utils.py:64-66). */
+ * (transformer_utils.py:64-66).  wgroup_rows > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use
+ * w + g*D, b + g*D (the four heads normalised in one launch). */
 int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
-                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int dtype, mk_stream_t stream);
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int dtype,
+                 mk_stream_t stream);
 
 /* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
  * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
@@ -153,10 +155,12 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
                     int C, int n0, int n1, mk_stream_t stream);
 
 /* sinkhorn.forward (feature_matcher.py:93-137): 10 log-domain iterations on u, v only.
+ *   scr0/scr1/kp_scores/final_scores as in mk_dual_softmax (optional).
  *   work: mk_sinkhorn_work_floats(B, n0, n1) fp32 elements (holds the (n0+1)x(n1+1) coupling matrix). */
 long long mk_sinkhorn_work_floats(int B, int n0, int n1);
-int mk_sinkhorn(const float* dsc0, const float* dsc1, float alpha, int iters, float* scores, float* work, int B, int C,
-                int n0, int n1, mk_stream_t stream);
+int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float alpha, int iters,
+                float* scores, float* kp_scores, float* final_scores, float* work, int B, int C, int n0, int n1,
+                mk_stream_t stream);
 
 /* featureMatcher.get_matches_list (feature_matcher.py:19-46), batched: mutual nearest neighbours on
  * scores[b, :n0-1, :n1-1], sorted by score descending.  matches int32 [B, n0, 2] (row i, col j),
@@ -177,10 +181,13 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  *   idx    int32 [B*rows_per_pair, k];  cnt int32 [B*rows_per_pair] = number of non-zero-key entries
  *          actually available (< k only if fewer than k cells have p > 0; the tail is then filled
  *          with zero-probability cells in ascending index order)
- *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k) */
+ *   invalid int32 [1] or NULL: OR-ed with 1 when torch.multinomial would have raised (a NaN / inf /
+ *          negative probability, or a row without any positive cell) -- the reference then returns
+ *          the zero pose for the whole batch (probabilisticProcrustes.py:331-336)
+ *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k), 16-byte aligned */
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k);
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx,
-                    int* cnt, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream);
+                    int* cnt, int* invalid, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream);
 
 /* Index decode + gathers + back-projection (probabilisticProcrustes.py:233-244, training_utils.py:7-22):
  * for every sampled cell c = idx[r, s]: i = c / n1 (image-0 keypoint), j = c % n1;

@@ -27,7 +27,7 @@ SIGNATURES = {
     "mk_gemm_patch_embed": ("i", "pipipppiiiiip"),
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
-    "mk_layernorm": ("i", "pippfpiipiiiiiip"),
+    "mk_layernorm": ("i", "pippfpiipiiiiiiip"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_conv3x3": ("i", "pliplipilplppiliiiiiipip"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
@@ -38,10 +38,10 @@ SIGNATURES = {
     "mk_dual_softmax_work_floats": ("l", "iii"),
     "mk_dual_softmax": ("i", "ppppfifppppiiiip"),
     "mk_sinkhorn_work_floats": ("l", "iii"),
-    "mk_sinkhorn": ("i", "ppfippiiiip"),
+    "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iii"),
-    "mk_exprace_topk": ("i", "ppuupppiilip"),
+    "mk_exprace_topk": ("i", "ppuuppppiilip"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),
     "mk_ransac_hypotheses": ("i", "pppppuufppppiiip"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),

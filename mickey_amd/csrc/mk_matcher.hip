@@ -253,13 +253,22 @@ __global__ __launch_bounds__(256) void sink_col_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void sink_final_kernel(const float* __restrict__ Z, const float* __restrict__ u,
-                                                         const float* __restrict__ v, float norm, float* __restrict__ out,
-                                                         int n0, int n1) {
+                                                         const float* __restrict__ v, float norm,
+                                                         const float* __restrict__ scr0, const float* __restrict__ scr1,
+                                                         float* __restrict__ out, float* __restrict__ kp,
+                                                         float* __restrict__ fin, int n0, int n1) {
   const int b = blockIdx.z, i = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n1) return;
   const float z = Z[((long long)b * (n0 + 1) + i) * (n1 + 1) + j];
-  out[((long long)b * n0 + i) * n1 + j] = expf(z + u[(long long)b * (n0 + 1) + i] + v[(long long)b * (n1 + 1) + j] - norm);
+  const float pr = expf(z + u[(long long)b * (n0 + 1) + i] + v[(long long)b * (n1 + 1) + j] - norm);
+  const long long o = ((long long)b * n0 + i) * n1 + j;
+  if (out) out[o] = pr;
+  if (scr0) {
+    const float kk = scr0[(long long)b * n0 + i] * scr1[(long long)b * n1 + j];
+    if (kp) kp[o] = kk;
+    if (fin) fin[o] = pr * kk;
+  }
 }
 
 __global__ void fill_kernel(float* p, float v, long long n) {
@@ -401,9 +410,10 @@ long long mk_sinkhorn_work_floats(int B, int n0, int n1) {
   return (long long)B * ((long long)(n0 + 1) * (n1 + 1) + (n0 + 1) + (n1 + 1));
 }
 
-int mk_sinkhorn(const float* dsc0, const float* dsc1, float alpha, int iters, float* scores, float* work, int B, int C, int n0,
-                int n1, mk_stream_t stream) {
-  MK_CHECK_ARG(dsc0 && dsc1 && scores && work, "mk_sinkhorn: null pointer");
+int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float alpha, int iters, float* scores,
+                float* kp_scores, float* final_scores, float* work, int B, int C, int n0, int n1, mk_stream_t stream) {
+  MK_CHECK_ARG(dsc0 && dsc1 && work && (scores || final_scores), "mk_sinkhorn: null pointer");
+  MK_CHECK_ARG((scr0 && scr1) || (!kp_scores && !final_scores), "mk_sinkhorn: kp/final scores need scr0 and scr1");
   MK_CHECK_ARG(B > 0 && n0 > 0 && n1 > 0 && C > 0 && C <= CMAX && C % 2 == 0 && iters >= 0, "mk_sinkhorn: bad args");
   hipStream_t st = (hipStream_t)stream;
   float* Z = work;
@@ -423,7 +433,8 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, float alpha, int iters, fl
     hipLaunchKernelGGL(sink_col_kernel, dim3((n1 + 1 + 63) / 64, B), dim3(256), 0, st, Z, u, v, n0, n1, norm, log_nu_last);
   }
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, Z, u, v, norm, scores, n0, n1);
+  hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, Z, u, v, norm, scr0, scr1, scores, kp_scores,
+                     final_scores, n0, n1);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

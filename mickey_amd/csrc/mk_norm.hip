@@ -15,13 +15,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
-                                                        int rows_per_img, int skip) {
+                                                        int rows_per_img, int skip, int wgroup_rows) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows_out) return;
   const int rpo = rows_per_img - skip;
   const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
   const float* xr = x + rin * ldx;
+  if (wgroup_rows > 0) {  // one (w, b) per block of wgroup_rows output rows
+    w += (long long)(r / wgroup_rows) * D;
+    b += (long long)(r / wgroup_rows) * D;
+  }
   f32x4 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
@@ -126,7 +130,8 @@ int mk_version(void) { return 100; }
 const char* mk_last_error(void) { return g_err; }
 
 int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
-                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int dtype, mk_stream_t stream) {
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int dtype,
+                 mk_stream_t stream) {
   MK_CHECK_ARG(x && w && b && (out || resid), "mk_layernorm: null pointer");
   MK_CHECK_ARG(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, "mk_layernorm: D=%d must be a multiple of 4 and <= %d", D,
                LN_MAXV * 256);
@@ -135,10 +140,10 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
   dim3 grid((rows_out + 3) / 4);
   if (dtype == MK_BF16)
     hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
-                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip);
+                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows);
   else
     hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
-                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip);
+                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

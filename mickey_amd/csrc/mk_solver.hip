@@ -1,0 +1,665 @@
+// mickey_amd -- probabilistic-Procrustes RANSAC on gfx950
+// (reference lib/models/MicKey/modules/utils/probabilisticProcrustes.py:183-348).
+//
+// The reference materialises a [20B, n*n] tiled copy of final_scores (300 MB / pair), a same-sized
+// Exp(1) noise tensor and a full top-k for its outer torch.multinomial, then tiles X/Y 100x for the
+// inner one.  Here:
+//   * mk_exprace_topk: ONE streamed read of final_scores per group of 4 rows, Philox noise generated
+//     in registers, radix-histogram threshold + small in-LDS bitonic sort -> the same "top-k of
+//     p / Exp(1)" selection, in the same (descending key) order torch.topk returns.
+//   * mk_ransac_hypotheses: a correspondence set (X, Y, w: 56 KB) is staged once in LDS and shared by
+//     all its hypotheses; one wave per hypothesis: exponential-race 3-sample (wave arg-max), 3x3
+//     Kabsch via one-sided Jacobi SVD in fp64 (warp-serial, no MFMA), soft inlier count by wave64
+//     reduction.
+//   * mk_refine_pose: one workgroup per pair: arg-max, <= 4 masked-Kabsch refits with the reference's
+//     per-pair early exit, final confidence.  No host synchronisation anywhere.
+// Noise can be INJECTED (fp32 Exp(1) tensors / explicit indices) so that tests are bit-comparable
+// with torch; the product path uses Philox4x32-10.
+#include "mk_common.hpp"
+
+#pragma clang fp contract(off)  // keep p/e, dist, sigmoid arithmetic un-fused: comparable with ATen
+
+namespace {
+using namespace mk;
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32(unsigned k0, unsigned k1, U4 c) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// Exp(1) draw from 32 random bits: u in (0,1) on a 2^-24 grid, e = -log(u) > 0
+__device__ __forceinline__ float exp1(unsigned r) { return -logf(((float)(r >> 8) + 0.5f) * 5.9604644775390625e-8f); }
+
+// ---- exponential-race top-k -------------------------------------------------------------------------
+constexpr int NBINS = 2048;     // bits 30..20 of a positive float: exponent + 3 mantissa bits
+constexpr int RG = 4;           // rows per group = draws per Philox call
+constexpr int CAND_MAX = 8192;  // candidates kept per row (expected ~k * 1.1)
+constexpr int CELL_BLOCKS = 128;
+
+struct TopkWork {
+  unsigned* hist;            // [R][NBINS]
+  int* thr;                  // [R]
+  unsigned* ncand;           // [R]
+  unsigned long long* cand;  // [R][CAND_MAX]
+  int* invalid;              // [1] or null
+};
+
+__device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsigned k0, unsigned k1, unsigned off_lo,
+                                         unsigned off_hi, float p, long long c, long long ncell, int b, int rows_per_pair,
+                                         int grp, float key[RG]) {
+  if (noise) {
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int r = grp * RG + q;
+      key[q] = r < rows_per_pair ? p / noise[((long long)b * rows_per_pair + r) * ncell + c] : 0.f;
+    }
+  } else {
+    const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, (unsigned)(c >> 32) ^ off_hi, (unsigned)(b * 64 + grp), off_lo});
+    key[0] = p / exp1(rnd.x);
+    key[1] = p / exp1(rnd.y);
+    key[2] = p / exp1(rnd.z);
+    key[3] = p / exp1(rnd.w);
+  }
+}
+
+template <int PASS>  // 0: histogram, 1: collect
+__global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restrict__ p, const float* __restrict__ noise,
+                                                           unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
+                                                           TopkWork w, int rows_per_pair, long long ncell) {
+  __shared__ unsigned sh[RG * NBINS];
+  const int b = blockIdx.z, grp = blockIdx.y;
+  const long long per = (ncell + gridDim.x - 1) / gridDim.x;
+  const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
+  int thr[RG];
+  if (PASS == 0) {
+    for (int i = threadIdx.x; i < RG * NBINS; i += 256) sh[i] = 0;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int r = grp * RG + q;
+      thr[q] = r < rows_per_pair ? w.thr[b * rows_per_pair + r] : NBINS;
+    }
+  }
+  const float* pb = p + (long long)b * ncell;
+  for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
+    const float pv = pb[c];
+    if (PASS == 0 && w.invalid && grp == 0 && (!(pv >= 0.f) || isinf(pv))) atomicOr(w.invalid, 1);
+    if (!(pv > 0.f) || isinf(pv)) continue;
+    float key[RG];
+    row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key);
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int r = grp * RG + q;
+      if (r >= rows_per_pair) continue;
+      const unsigned bits = __float_as_uint(key[q]);
+      const int bin = (int)((bits & 0x7fffffffu) >> 20);
+      if (PASS == 0) {
+        atomicAdd(&sh[q * NBINS + bin], 1u);
+      } else if (bin >= thr[q]) {
+        const int row = b * rows_per_pair + r;
+        const unsigned slot = atomicAdd(&w.ncand[row], 1u);
+        if (slot < CAND_MAX)
+          w.cand[(long long)row * CAND_MAX + slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+      }
+    }
+  }
+  if (PASS == 0) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < RG * NBINS; i += 256) {
+      const int q = i / NBINS, r = grp * RG + q;
+      if (sh[i] && r < rows_per_pair) atomicAdd(&w.hist[((long long)b * rows_per_pair + r) * NBINS + (i % NBINS)], sh[i]);
+    }
+  }
+}
+
+// one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
+__global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k) {
+  __shared__ unsigned part[256];
+  const int row = blockIdx.x, t = threadIdx.x;
+  const unsigned* h = w.hist + (long long)row * NBINS;
+  // thread t owns bins [t*8, t*8+8); suffix sums from the top
+  unsigned loc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) loc += h[t * 8 + i];
+  part[t] = loc;
+  __syncthreads();
+  if (t == 0) {
+    unsigned run = 0;
+    int tb = 0;
+    for (int s = 255; s >= 0; --s) {
+      if (run + part[s] >= (unsigned)k) {
+        for (int i = 7; i >= 0; --i) {
+          run += h[s * 8 + i];
+          if (run >= (unsigned)k) { tb = s * 8 + i; break; }
+        }
+        break;
+      }
+      run += part[s];
+    }
+    w.thr[row] = tb;
+  }
+}
+
+// one block per row: sort the candidates (key desc, index asc), emit the top k
+__global__ __launch_bounds__(1024) void exprace_select_kernel(const float* __restrict__ p, TopkWork w, int* __restrict__ idx,
+                                                              int* __restrict__ cnt, int rows_per_pair, long long ncell,
+                                                              int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int row = blockIdx.x;
+  const unsigned nc_raw = w.ncand[row];
+  const int nc = (int)min(nc_raw, (unsigned)CAND_MAX);
+  int np2 = 1;
+  while (np2 < nc) np2 <<= 1;
+  if (np2 < 2) np2 = 2;
+  const unsigned long long* cand = w.cand + (long long)row * CAND_MAX;
+  for (int i = threadIdx.x; i < np2; i += 1024) keys[i] = i < nc ? cand[i] : 0ull;
+  __syncthreads();
+  for (int kk = 2; kk <= np2; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool desc = (i & kk) == 0;
+          if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int take = min(nc, k);
+  for (int i = threadIdx.x; i < take; i += 1024)
+    idx[(long long)row * k + i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffu));
+  if (threadIdx.x == 0) {
+    cnt[row] = nc_raw > (unsigned)CAND_MAX ? -1 : take;
+    if (nc_raw == 0 && w.invalid) atomicOr(w.invalid, 1);
+    if (take < k) {  // degenerate: fewer than k cells with p > 0 -> pad with zero-probability cells
+      const float* pb = p + (long long)(row / rows_per_pair) * ncell;
+      int f = take;
+      for (long long c = 0; c < ncell && f < k; ++c)
+        if (!(pb[c] > 0.f)) idx[(long long)row * k + f++] = (int)c;
+      for (; f < k; ++f) idx[(long long)row * k + f] = 0;
+    }
+  }
+}
+
+__global__ void zero_u32_kernel(unsigned* p, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+// ---- gather + back-projection -----------------------------------------------------------------------
+__device__ __forceinline__ void inv3(const float* K, float* o) {
+  const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+  const float det = a * A + b * Bc + c * Cc;
+  const float id = 1.0f / det;
+  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+  o[3] = Bc * id; o[4] = (a * i - c * g) * id; o[5] = -(a * f - c * d) * id;
+  o[6] = Cc * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+
+__global__ __launch_bounds__(256) void gather_backproject_kernel(const int* __restrict__ idx, const float* __restrict__ fs,
+                                                                 const float* __restrict__ kps0, const float* __restrict__ dep0,
+                                                                 const float* __restrict__ kps1, const float* __restrict__ dep1,
+                                                                 const float* __restrict__ K0, const float* __restrict__ K1,
+                                                                 float* __restrict__ X, float* __restrict__ Y,
+                                                                 float* __restrict__ wts, float* __restrict__ corr,
+                                                                 int rows_per_pair, int k, int n0, int n1) {
+  const int r = blockIdx.y, b = r / rows_per_pair;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= k) return;
+  float Ki0[9], Ki1[9];
+  inv3(K0 + b * 9, Ki0);
+  inv3(K1 + b * 9, Ki1);
+  const int c = idx[(long long)r * k + s];
+  const int i = c / n1, j = c - i * n1;
+  const float u0 = kps0[((long long)b * 2 + 0) * n0 + i], v0 = kps0[((long long)b * 2 + 1) * n0 + i], d0 = dep0[(long long)b * n0 + i];
+  const float u1 = kps1[((long long)b * 2 + 0) * n1 + j], v1 = kps1[((long long)b * 2 + 1) * n1 + j], d1 = dep1[(long long)b * n1 + j];
+  const long long o = (long long)r * k + s;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    X[o * 3 + a] = d0 * (Ki0[a * 3 + 0] * u0 + Ki0[a * 3 + 1] * v0 + Ki0[a * 3 + 2]);
+    Y[o * 3 + a] = d1 * (Ki1[a * 3 + 0] * u1 + Ki1[a * 3 + 1] * v1 + Ki1[a * 3 + 2]);
+  }
+  wts[o] = fs[(long long)b * n0 * n1 + c];
+  float* cr = corr + o * 6;
+  cr[0] = u0; cr[1] = v0; cr[2] = u1; cr[3] = v1; cr[4] = d0; cr[5] = d1;
+}
+
+// ---- 3x3 Kabsch: R = V diag(1,1,det(V U^T)) U^T for H = U S V^T (reference loss/solvers.py:45-50) ----
+// One-sided Jacobi on the columns of H (no H^T H: keeps fp32-level relative accuracy of the small
+// singular directions), fp64, then the two leading singular pairs + right-handed completion, which
+// equals the reflection-fixed Kabsch rotation and is finite for degenerate (collinear) input.
+__device__ void kabsch_rotation(const double Hin[9], double R[9]) {
+  double G[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = Hin[i];
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      double al = 0, be = 0, ga = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        al += G[r * 3 + p] * G[r * 3 + p];
+        be += G[r * 3 + q] * G[r * 3 + q];
+        ga += G[r * 3 + p] * G[r * 3 + q];
+      }
+      if (fabs(ga) <= 1e-30 || ga * ga <= 1e-32 * al * be) continue;
+      off += fabs(ga);
+      const double zeta = (be - al) / (2.0 * ga);
+      const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double gp = G[r * 3 + p], gq = G[r * 3 + q];
+        G[r * 3 + p] = cs * gp - sn * gq;
+        G[r * 3 + q] = sn * gp + cs * gq;
+        const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+        V[r * 3 + p] = cs * vp - sn * vq;
+        V[r * 3 + q] = sn * vp + cs * vq;
+      }
+    }
+    if (off == 0.0) break;
+  }
+  double nrm[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) nrm[c] = G[c] * G[c] + G[3 + c] * G[3 + c] + G[6 + c] * G[6 + c];
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (nrm[i0] < nrm[i1]) { int t = i0; i0 = i1; i1 = t; }
+  if (nrm[i0] < nrm[i2]) { int t = i0; i0 = i2; i2 = t; }
+  if (nrm[i1] < nrm[i2]) { int t = i1; i1 = i2; i2 = t; }
+  double u1[3], u2[3], v1[3], v2[3];
+  const double s1 = sqrt(nrm[i0]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    v1[r] = V[r * 3 + i0];
+    v2[r] = V[r * 3 + i1];
+    u1[r] = s1 > 1e-300 ? G[r * 3 + i0] / s1 : (r == 0 ? 1.0 : 0.0);
+    u2[r] = G[r * 3 + i1];
+  }
+  // u2: orthogonalise against u1 and normalise; fall back to any perpendicular if it vanishes
+  double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) u2[r] -= d12 * u1[r];
+  double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  if (!(n2 > 1e-12 * s1) || !(n2 > 1e-300)) {
+    const int ax = fabs(u1[0]) <= fabs(u1[1]) && fabs(u1[0]) <= fabs(u1[2]) ? 0 : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[ax] = 1.0;
+    d12 = u1[ax];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u2[r] = e[r] - d12 * u1[r];
+    n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) u2[r] /= n2;
+  const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+  const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[a * 3 + b] = v1[a] * u1[b] + v2[a] * u2[b] + v3[a] * u3[b];
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// dist_j = sqrt(|R x + t - y|^2 + 1e-6)   (reference training_utils.py:58-59)
+__device__ __forceinline__ float pt_dist(const float* R, const float* t, const float* x, const float* y) {
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float v = (R[a * 3 + 0] * x[0] + R[a * 3 + 1] * x[1] + R[a * 3 + 2] * x[2]) + t[a] - y[a];
+    s += v * v;
+  }
+  return sqrtf(s + 1e-6f);
+}
+
+// ---- hypotheses: block = (set r, slice of its hypotheses); wave = hypothesis -------------------------
+__global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                         const float* __restrict__ wts, const float* __restrict__ noise3,
+                                                         const int* __restrict__ idx3_in, unsigned k0, unsigned k1,
+                                                         unsigned off_lo, unsigned off_hi, float th_soft, float* __restrict__ Rh,
+                                                         float* __restrict__ th, float* __restrict__ score,
+                                                         int* __restrict__ idx3, int it_ransac, int k, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // X[k*3] | Y[k*3] | w[k]
+  float* sX = lds;
+  float* sY = lds + (size_t)k * 3;
+  float* sW = lds + (size_t)k * 6;
+  const int r = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < k * 3; i += 256) {
+    sX[i] = X[(long long)r * k * 3 + i];
+    sY[i] = Y[(long long)r * k * 3 + i];
+  }
+  for (int i = threadIdx.x; i < k; i += 256) sW[i] = wts[(long long)r * k + i];
+  __syncthreads();
+  const int per = (it_ransac + nsplit - 1) / nsplit;
+  const int h0 = part * per, h1 = min(it_ransac, h0 + per);
+  const float beta = 5.0f / th_soft;
+  for (int h = h0 + wave; h < h1; h += 4) {
+    const long long hyp = (long long)r * it_ransac + h;
+    int sel[3];
+    if (idx3_in) {
+      sel[0] = idx3_in[hyp * 3 + 0];
+      sel[1] = idx3_in[hyp * 3 + 1];
+      sel[2] = idx3_in[hyp * 3 + 2];
+    } else {
+      // per-lane top-3 of key = w / e, then 3 wave arg-max rounds
+      float bk[3] = {-1.f, -1.f, -1.f};
+      int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+      for (int base = lane * 4; base < k; base += 256) {
+        float e[4];
+        if (noise3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = base + q < k ? noise3[hyp * k + base + q] : 1.f;
+        } else {
+          const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(base >> 2), (unsigned)hyp, (unsigned)(hyp >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
+          e[0] = exp1(rnd.x); e[1] = exp1(rnd.y); e[2] = exp1(rnd.z); e[3] = exp1(rnd.w);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = base + q;
+          if (j >= k) continue;
+          const float key = sW[j] / e[q];
+          if (key > bk[2]) {  // strict: earlier (lower) index wins ties
+            if (key > bk[0]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = bk[0]; bi[1] = bi[0]; bk[0] = key; bi[0] = j; }
+            else if (key > bk[1]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = key; bi[1] = j; }
+            else { bk[2] = key; bi[2] = j; }
+          }
+        }
+      }
+#pragma unroll
+      for (int round = 0; round < 3; ++round) {
+        float v = bk[0];
+        int ix = bi[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float v2 = __shfl_xor(v, o, 64);
+          const int i2 = __shfl_xor(ix, o, 64);
+          if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        }
+        sel[round] = ix;
+        if (bi[0] == ix) { bk[0] = bk[1]; bi[0] = bi[1]; bk[1] = bk[2]; bi[1] = bi[2]; bk[2] = -1.f; bi[2] = 0x7fffffff; }
+      }
+    }
+    // Kabsch on the 3 pairs, computed redundantly by every lane (reference loss/solvers.py:31-39,45-52)
+    float am[3], bm[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      am[a] = (sX[sel[0] * 3 + a] + sX[sel[1] * 3 + a] + sX[sel[2] * 3 + a]) / 3.0f;
+      bm[a] = (sY[sel[0] * 3 + a] + sY[sel[1] * 3 + a] + sY[sel[2] * 3 + a]) / 3.0f;
+    }
+    double H[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int pnt = 0; pnt < 3; ++pnt) s += (sX[sel[pnt] * 3 + a] - am[a]) * (sY[sel[pnt] * 3 + c] - bm[c]);
+        H[a * 3 + c] = (double)s;
+      }
+    double Rd[9];
+    kabsch_rotation(H, Rd);
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) tf[a] = bm[a] - (am[0] * Rf[a * 3 + 0] + am[1] * Rf[a * 3 + 1] + am[2] * Rf[a * 3 + 2]);
+    float sc = 0.f;
+    for (int j = lane; j < k; j += 64) sc += sigmoidf(beta * (th_soft - pt_dist(Rf, tf, sX + j * 3, sY + j * 3)));
+    sc = wave_sum(sc);
+    if (lane < 9) Rh[hyp * 9 + lane] = Rf[lane];
+    if (lane < 3) { th[hyp * 3 + lane] = tf[lane]; idx3[hyp * 3 + lane] = sel[lane]; }
+    if (lane == 0) score[hyp] = sc;
+  }
+}
+
+// ---- arg-max + refinement: one workgroup per pair -----------------------------------------------------
+constexpr int RT = 512;
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int i = 0; i < RT / 64; ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(RT) void refine_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                    const float* __restrict__ Rh, const float* __restrict__ th,
+                                                    const float* __restrict__ score, float th_in, int num_ref, int min_inl,
+                                                    float* __restrict__ Ro, float* __restrict__ to, float* __restrict__ conf,
+                                                    int* __restrict__ best, unsigned char* __restrict__ mask,
+                                                    int* __restrict__ rounds, int* __restrict__ invalid, int it_matches,
+                                                    int it_ransac, int k) {
+  __shared__ double red[RT / 64];
+  __shared__ float sv[RT / 64];
+  __shared__ int si[RT / 64];
+  __shared__ float sR[9], st[3];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HP = it_matches * it_ransac;
+  // non-finite hypothesis anywhere in the batch -> the reference returns the zero pose for all pairs
+  bool bad = false;
+  for (int i = tid; i < HP * 9; i += RT) bad |= !isfinite(Rh[(long long)b * HP * 9 + i]);
+  for (int i = tid; i < HP * 3; i += RT) bad |= !isfinite(th[(long long)b * HP * 3 + i]);
+  if (bad) atomicOr(invalid, 1);
+  // arg-max (first index among equal maxima)
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < HP; i += RT) {
+    const float v = score[(long long)b * HP + i];
+    if (v > bv) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(bv, o, 64);
+    const int i2 = __shfl_xor(bi, o, 64);
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < RT / 64; ++i)
+      if (sv[i] > bv || (sv[i] == bv && si[i] < bi)) { bv = sv[i]; bi = si[i]; }
+    if (bi == 0x7fffffff) bi = 0;  // all-NaN scores
+    si[0] = bi;
+    for (int i = 0; i < 9; ++i) sR[i] = Rh[((long long)b * HP + bi) * 9 + i];
+    for (int i = 0; i < 3; ++i) st[i] = th[((long long)b * HP + bi) * 3 + i];
+  }
+  __syncthreads();
+  const int hb = si[0];
+  const long long set = (long long)b * it_matches + hb / it_ransac;
+  const float* Xb = X + set * k * 3;
+  const float* Yb = Y + set * k * 3;
+  float best_cnt = (float)min_inl;
+  int nround = 0;
+  for (int it = 0; it < num_ref; ++it) {
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = sR[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = st[i];
+    double cnt = 0, sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+    for (int j = tid; j < k; j += RT) {
+      if (th_in - pt_dist(R, t, Xb + j * 3, Yb + j * 3) >= 0.f) {
+        cnt += 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sa[a] += Xb[j * 3 + a]; sb[a] += Yb[j * 3 + a]; }
+      }
+    }
+    const double C = block_sum_d(cnt, red);
+    if (!(C >= (double)min_inl && C > (double)best_cnt)) break;  // block-uniform
+    best_cnt = (float)C;
+    ++nround;
+    // weighted centroids with w / (sum|w| + 1e-16), covariance with the RAW 0/1 mask (solvers.py:14-26)
+    double am[3], bm[3];
+    const float wn = 1.0f / ((float)C + 1e-16f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      am[a] = block_sum_d(sa[a], red) * (double)wn;
+      bm[a] = block_sum_d(sb[a], red) * (double)wn;
+    }
+    double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = tid; j < k; j += RT) {
+      if (th_in - pt_dist(R, t, Xb + j * 3, Yb + j * 3) >= 0.f) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) hl[a * 3 + c] += ((double)Xb[j * 3 + a] - am[a]) * ((double)Yb[j * 3 + c] - bm[c]);
+      }
+    }
+    double H[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = block_sum_d(hl[i], red);
+    __syncthreads();
+    if (tid == 0) {
+      double Rd[9];
+      kabsch_rotation(H, Rd);
+      for (int i = 0; i < 9; ++i) sR[i] = (float)Rd[i];
+      for (int a = 0; a < 3; ++a)
+        st[a] = (float)bm[a] - ((float)am[0] * sR[a * 3 + 0] + (float)am[1] * sR[a * 3 + 1] + (float)am[2] * sR[a * 3 + 2]);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  float R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = sR[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = st[i];
+  const float beta = 5.0f / th_in;
+  double cs = 0;
+  for (int j = tid; j < k; j += RT) {
+    const float d = pt_dist(R, t, Xb + j * 3, Yb + j * 3);
+    cs += (double)sigmoidf(beta * (th_in - d));
+    mask[(long long)b * k + j] = (th_in - d) >= 0.f ? 1 : 0;
+  }
+  const double ctot = block_sum_d(cs, red);
+  if (tid < 9) Ro[b * 9 + tid] = R[tid];
+  if (tid < 3) to[b * 3 + tid] = t[tid];
+  if (tid == 0) { conf[b] = (float)ctot; best[b] = hb; rounds[b] = nround; }
+}
+
+__global__ void finalize_kernel(float* R, float* t, float* conf, const int* invalid, int B) {
+  if (*invalid == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 9) R[i] = 0.f;
+  if (i < B * 3) t[i] = 0.f;
+  if (i < B) conf[i] = 0.f;
+}
+
+TopkWork carve(void* work, int R) {
+  TopkWork w;
+  char* p = (char*)work;
+  w.hist = (unsigned*)p;  p += (size_t)R * NBINS * 4;
+  w.thr = (int*)p;        p += (size_t)R * 4;
+  w.ncand = (unsigned*)p; p += (size_t)R * 4;
+  p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  w.cand = (unsigned long long*)p;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k) {
+  (void)k;
+  const long long R = (long long)B * rows_per_pair;
+  return R * NBINS * 4 + R * 8 + 16 + R * CAND_MAX * 8;
+}
+
+int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx, int* cnt,
+                    int* invalid, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream) {
+  MK_CHECK_ARG(p && idx && cnt && work, "mk_exprace_topk: null pointer");
+  MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && rows_per_pair <= 64 * RG && ncell > 0 && ncell < (1LL << 31) && k > 0 &&
+                   k <= CAND_MAX / 2,
+               "mk_exprace_topk: bad sizes (k <= %d, ncell < 2^31)", CAND_MAX / 2);
+  MK_CHECK_ARG(((uintptr_t)work & 15) == 0, "mk_exprace_topk: work must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = B * rows_per_pair;
+  TopkWork w = carve(work, R);
+  w.invalid = invalid;
+  const long long nz = (long long)R * NBINS + 2LL * R;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand are contiguous
+  MK_CHECK_LAUNCH();
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), ol = (unsigned)offset, oh = (unsigned)(offset >> 32);
+  const int groups = (rows_per_pair + RG - 1) / RG;
+  int cb = CELL_BLOCKS;
+  if ((long long)cb * 256 > ncell) cb = (int)((ncell + 255) / 256);
+  dim3 grid(cb, groups, B);
+  hipLaunchKernelGGL(exprace_scan_kernel<0>, grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(exprace_scan_kernel<1>, grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(1024), (size_t)CAND_MAX * 8, st, p, w, idx, cnt, rows_per_pair, ncell,
+                     k);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_gather_backproject(const int* idx, const float* final_scores, const float* kps0, const float* depth0, const float* kps1,
+                          const float* depth1, const float* K0, const float* K1, float* X, float* Y, float* wts, float* corr,
+                          int B, int rows_per_pair, int k, int n0, int n1, mk_stream_t stream) {
+  MK_CHECK_ARG(idx && final_scores && kps0 && depth0 && kps1 && depth1 && K0 && K1 && X && Y && wts && corr,
+               "mk_gather_backproject: null pointer");
+  MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && k > 0 && n0 > 0 && n1 > 0, "mk_gather_backproject: bad sizes");
+  hipLaunchKernelGGL(gather_backproject_kernel, dim3((k + 255) / 256, B * rows_per_pair), dim3(256), 0, (hipStream_t)stream, idx,
+                     final_scores, kps0, depth0, kps1, depth1, K0, K1, X, Y, wts, corr, rows_per_pair, k, n0, n1);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
+                         unsigned long long seed, unsigned long long offset, float th_soft, float* Rh, float* th, float* score,
+                         int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream) {
+  MK_CHECK_ARG(X && Y && wts && Rh && th && score && idx3, "mk_ransac_hypotheses: null pointer");
+  MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 28 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 5485)");
+  const int nsplit = it_ransac >= 16 ? 4 : 1;
+  const size_t lds = (size_t)k * 7 * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)hypotheses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { mk_set_error("mk_ransac_hypotheses: cannot reserve %zu B of LDS", lds); return MK_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL(hypotheses_kernel, dim3(nsets * nsplit), dim3(256), lds, (hipStream_t)stream, X, Y, wts, noise3, idx3_in,
+                     (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), th_soft, Rh, th, score,
+                     idx3, it_ransac, k, nsplit);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_refine_pose(const float* X, const float* Y, const float* Rh, const float* th, const float* score, float th_inlier,
+                   int num_ref, int min_inliers, float* R, float* t, float* conf, int* best, unsigned char* inl_mask, int* rounds,
+                   int* invalid, int B, int it_matches, int it_ransac, int k, mk_stream_t stream) {
+  MK_CHECK_ARG(X && Y && Rh && th && score && R && t && conf && best && inl_mask && rounds && invalid,
+               "mk_refine_pose: null pointer");
+  MK_CHECK_ARG(B > 0 && it_matches > 0 && it_ransac > 0 && k > 0 && num_ref >= 0, "mk_refine_pose: bad sizes");
+  hipLaunchKernelGGL(refine_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, X, Y, Rh, th, score, th_inlier, num_ref,
+                     min_inliers, R, t, conf, best, inl_mask, rounds, invalid, it_matches, it_ransac, k);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_pose_finalize(float* R, float* t, float* conf, const int* invalid, int B, mk_stream_t stream) {
+  MK_CHECK_ARG(R && t && conf && invalid && B > 0, "mk_pose_finalize: bad args");
+  hipLaunchKernelGGL(finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, t, conf, invalid, B);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+}  // extern "C"

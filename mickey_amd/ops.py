@@ -73,10 +73,10 @@ def cls_token(cls, pos, x, nimg, ntok, D):
 
 
 def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows_out=None, rows_per_img=None, skip=0,
-              ldo=None):
+              ldo=None, wgroup_rows=0, ldx=None, ldr=None):
     """LayerNorm rows of fp32 x [rows, D]; see mk_layernorm for the row remap and the residual form."""
-    D = w.shape[0]
-    rows_in = x.shape[0]
+    D = w.shape[-1]
+    rows_in = x.numel() // x.shape[-1]
     if rows_per_img is None:
         rows_per_img = rows_in
     if rows_out is None:
@@ -84,10 +84,11 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
     if out is None and out_dtype is not None:
         out = torch.empty((rows_out, D), device=x.device, dtype=out_dtype)
     is_f32 = out is not None and out.dtype == torch.float32
-    ldo = (out.stride(0) if out is not None else D) if ldo is None else ldo
+    ldo = (out.stride(-2) if out is not None else D) if ldo is None else ldo
     lp = out.dtype if (out is not None and not is_f32) else torch.bfloat16
-    call("mk_layernorm", ptr(x), x.stride(0), ptr(w), ptr(b), float(eps), ptr(out), ldo, int(is_f32), ptr(resid),
-         resid.stride(0) if resid is not None else D, rows_out, D, rows_per_img, skip, dtype_code(lp), stream())
+    call("mk_layernorm", ptr(x), x.stride(-2) if ldx is None else ldx, ptr(w), ptr(b), float(eps), ptr(out), ldo, int(is_f32),
+         ptr(resid), (resid.stride(-2) if resid is not None else D) if ldr is None else ldr, rows_out, D, rows_per_img, skip,
+         wgroup_rows, dtype_code(lp), stream())
     return out
 
 
@@ -154,13 +155,17 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
     return scores, kp, fin
 
 
-def sinkhorn(dsc0, dsc1, alpha, iters=10):
+def sinkhorn(dsc0, dsc1, alpha, iters=10, scr0=None, scr1=None, want_scores=True, want_kp=False, want_final=False):
+    """Returns scores, or (scores, kp_scores, final_scores) when scr0/scr1 are given."""
     B, C, n0 = dsc0.shape
     n1 = dsc1.shape[2]
-    out = torch.empty((B, n0, n1), device=dsc0.device, dtype=torch.float32)
-    work = torch.empty((query("mk_sinkhorn_work_floats", B, n0, n1),), device=dsc0.device, dtype=torch.float32)
-    call("mk_sinkhorn", ptr(dsc0), ptr(dsc1), float(alpha), int(iters), ptr(out), ptr(work), B, C, n0, n1, stream())
-    return out
+    dev = dsc0.device
+    mk = lambda want: torch.empty((B, n0, n1), device=dev, dtype=torch.float32) if want else None  # noqa: E731
+    out, kp, fin = mk(want_scores), mk(want_kp and scr0 is not None), mk(want_final and scr0 is not None)
+    work = torch.empty((query("mk_sinkhorn_work_floats", B, n0, n1),), device=dev, dtype=torch.float32)
+    call("mk_sinkhorn", ptr(dsc0), ptr(dsc1), ptr(scr0), ptr(scr1), float(alpha), int(iters), ptr(out), ptr(kp), ptr(fin),
+         ptr(work), B, C, n0, n1, stream())
+    return out if scr0 is None else (out, kp, fin)
 
 
 def mutual_nn(scores):
@@ -177,7 +182,7 @@ def mutual_nn(scores):
 
 # ---- solver ---------------------------------------------------------------------------------------
 
-def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0):
+def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None):
     """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
     _chk(p, torch.float32)
     B, ncell = p.shape
@@ -185,7 +190,7 @@ def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0):
     idx = torch.empty((B * rows_per_pair, k), device=dev, dtype=torch.int32)
     cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
     work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k),), device=dev, dtype=torch.uint8)
-    call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(idx), ptr(cnt), ptr(work), B, rows_per_pair,
+    call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(idx), ptr(cnt), ptr(invalid), ptr(work), B, rows_per_pair,
          ncell, k, stream())
     return idx, cnt
 
@@ -216,7 +221,7 @@ def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, 
     return Rh, th, score, idx3
 
 
-def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers):
+def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers, invalid=None):
     k = X.shape[1]
     dev = X.device
     R = torch.empty((B, 3, 3), device=dev, dtype=torch.float32)
@@ -225,7 +230,8 @@ def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_re
     best = torch.empty((B,), device=dev, dtype=torch.int32)
     mask = torch.empty((B, k), device=dev, dtype=torch.uint8)
     rounds = torch.empty((B,), device=dev, dtype=torch.int32)
-    invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
+    if invalid is None:
+        invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
     call("mk_refine_pose", ptr(X), ptr(Y), ptr(Rh), ptr(th), ptr(score), float(th_inlier), int(num_ref), int(min_inliers),
          ptr(R), ptr(t), ptr(conf), ptr(best), ptr(mask), ptr(rounds), ptr(invalid), B, it_matches, it_ransac, k, stream())
     call("mk_pose_finalize", ptr(R), ptr(t), ptr(conf), ptr(invalid), B, stream())

@@ -1,0 +1,196 @@
+"""Host-side orchestration of the HIP kernels for the MicKey hot path: which kernel runs on which
+buffer, in which order.  All arithmetic is in libmickey_hip.so; torch provides device memory and
+the stream only.  Mirrors (file:line under the reference):
+  encoder   DINO_modules/dinov2.py:191-236, layers/block.py:105-106
+  heads     mickey_extractor.py:53-58,126-140,166-178,202-218,237-251
+  matcher   compute_correspondences.py:52-92, compute_pose.py:23
+  solver    utils/probabilisticProcrustes.py:183-348
+"""
+import torch
+
+from . import ops
+from . import weights as wts_mod
+
+
+class Workspace:
+    """Per-shape device buffers, allocated once and reused across forward calls."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, shape, dtype, device, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None or t.device != device:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=device)
+            self.bufs[key] = t
+        return t
+
+
+def encoder_forward(W, ws, img):
+    """img fp32 [nimg, 3, H, W] on device (already cropped view or not: the /14 crop is implicit in
+    gh, gw).  Returns the final-norm patch tokens, lp [nimg*gh*gw, D] (NHWC feature map)."""
+    dev, lp = img.device, W.lp
+    nimg, _, H, Wd = img.shape
+    gh, gw = H // 14, Wd // 14
+    npatch, D, heads = gh * gw, W.D, W.heads
+    ntok = npatch + 1
+    pad = (ntok + 63) // 64 * 64
+    M = nimg * ntok
+    pos = wts_mod.interp_pos_embed(W, gh, gw, dev)
+    a = ops.im2col_patch14(img, gh, gw, wts_mod.PATCH_K, lp)
+    x = ws.get("x", (M, D), torch.float32, dev)
+    ops.gemm_patch_embed(a, W.patch_w, W.patch_b, pos, x, nimg, npatch)
+    ops.cls_token(W.cls, pos, x, nimg, ntok, D)
+    y = ws.get("y", (M, D), lp, dev)
+    att = ws.get("att", (M, D), lp, dev)
+    hid = ws.get("hid", (M, 4 * D), lp, dev)
+    q = ws.get("q", (nimg, heads, pad, 64), lp, dev, zero=True)   # pad rows stay zero forever
+    k = ws.get("k", (nimg, heads, pad, 64), lp, dev, zero=True)
+    vt = ws.get("vt", (nimg, heads, 64, pad), lp, dev, zero=True)
+    for blk in W.blocks:
+        ops.layernorm(x, blk.n1w, blk.n1b, 1e-6, out=y)
+        ops.gemm_qkv(y, blk.qkv_w, blk.qkv_b, q, k, vt, nimg, ntok, pad, heads)
+        ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
+        ops.gemm_ls_residual(att, blk.proj_w, blk.proj_b, blk.g1, x)
+        ops.layernorm(x, blk.n2w, blk.n2b, 1e-6, out=y)
+        ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
+        ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
+    feat = ws.get("feat", (nimg * npatch, D), lp, dev)
+    ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1)
+    return feat, gh, gw
+
+
+def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
+    """feat lp [nimg*n, D] -> scr [nimg,1,n], kps [nimg,2,n] (absolute pixels), depth [nimg,1,n],
+    dsc [nimg,Cd,n], all fp32."""
+    dev, lp = feat.device, W.lp
+    n = gh * gw
+    M = nimg * n
+    G = 4
+    mk = cfg["MICKEY"]
+    zp = W.zero_page
+    x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
+    for bi, rb in enumerate(W.rb):
+        co = rb.cout
+        h1 = ws.get("rb%d_h" % bi, (G, M, co), lp, dev)
+        ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, zp, act=ops.ACT_RELU, stride_in1=s_in,
+                    stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=M * co)
+        xo = ws.get("rb%d_x" % bi, (G, M, co), lp, dev)
+        ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, zp, act=ops.ACT_RELU, in2=x_in, C2=c_in,
+                    stride_in1=M * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
+                    stride_out=M * co)
+        x_in, c_in, s_in = xo, co, M * co
+    C = c_in  # 128
+    # ---- Transformer_self_att: 3 linear-attention encoder layers, residual stream in fp32 ----
+    xs = ws.get("att_xs", (G, M, C), torch.float32, dev)
+    cat = ws.get("att_cat", (G, M, 2 * C), lp, dev)
+    pe = wts_mod.sine_pos_table(W, C, gh, gw, dev)
+    kp_pe, dsc_pe = bool(mk["KP_HEADS"]["POS_ENCODING"]), bool(mk["DSC_HEAD"]["POS_ENCODING"])
+    if kp_pe == dsc_pe:
+        ops.posenc_add(x_in, pe if kp_pe else None, xs, cat, G, nimg, n, C)
+    else:
+        ops.posenc_add(x_in[:3], pe if kp_pe else None, xs[:3], cat[:3], 3, nimg, n, C)
+        ops.posenc_add(x_in[3:], pe if dsc_pe else None, xs[3:], cat[3:], 1, nimg, n, C)
+    qkv = ws.get("att_qkv", (G, M, 3 * C), torch.float32, dev)
+    kv = ws.get("att_kv", (G * nimg * (C // 16), 272), torch.float32, dev)
+    kvw = ws.get("att_kvw", (ops.linattn_work_floats(G, nimg, n, C),), torch.float32, dev)
+    msg = ws.get("att_msg", (G, M, C), lp, dev)
+    mrg = ws.get("att_mrg", (G, M, C), torch.float32, dev)
+    hid = ws.get("att_hid", (G, M, 2 * C), lp, dev)
+    x4 = ws.get("att_out", (G, M, C), lp, dev)
+    nl = len(W.att)
+    for li, lay in enumerate(W.att):
+        ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
+        ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
+        ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
+        ops.gemm_grouped(msg, lay.merge_w, None, mrg, G, M, C, C, C, C, C, M * C, C * C, 0, M * C)
+        ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
+                      wgroup_rows=M)
+        ops.gemm_grouped(cat, lay.mlp0_w, None, hid, G, M, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 4 * C * C, 0,
+                         M * 2 * C, act=ops.ACT_RELU)
+        ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
+        last = li == nl - 1
+        ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=x4 if last else cat, ldo=C if last else 2 * C, resid=xs,
+                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M)
+    # ---- resblock4 ----
+    kpw, dw = W.rb4_kp, W.rb4_dsc
+    ck = kpw.cout
+    h4 = ws.get("rb4_h", (3, M, ck), lp, dev)
+    ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, zp, act=ops.ACT_RELU, stride_in1=M * C,
+                stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=M * ck)
+    f4 = ws.get("rb4_f", (3, M, ck), torch.float32, dev)
+    ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, zp, act=ops.ACT_RELU,
+                in2=x4 if kpw.has_sc else None, C2=C, resid=None if kpw.has_sc else x4, stride_in1=M * ck,
+                stride_in2=M * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
+    cd = dw.cout
+    hd = ws.get("rb4_hd", (M, cd), lp, dev)
+    ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, zp, act=ops.ACT_RELU)
+    fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
+    ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, zp, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246
+                in2=x4[3] if dw.has_sc else None, C2=C, resid=None if dw.has_sc else x4[3])
+    kh = mk["KP_HEADS"]
+    return ops.head_tails(f4[0], W.w_score, f4[1], W.w_xy, f4[2], W.w_depth, fd, nimg, gh, gw, ck, cd, border=3,
+                          use_softmax=bool(kh["USE_SOFTMAX"]), use_depth_sigmoid=bool(kh["USE_DEPTHSIGMOID"]),
+                          max_depth=float(kh["MAX_DEPTH"]), norm_dsc=bool(mk["DSC_HEAD"]["NORM_DSC"]),
+                          down=float(mk["DINOV2"]["DOWN_FACTOR"]))
+
+
+def match(W, cfg, dsc0, dsc1, scr0, scr1, lean=False):
+    fm = cfg["FEATURE_MATCHER"]
+    if fm["TYPE"] == "DualSoftmax":
+        ds = fm["DUAL_SOFTMAX"]
+        return ops.dual_softmax(dsc0, dsc1, scr0, scr1, float(ds["TEMPERATURE"]), W.dustbin if ds["USE_DUSTBIN"] else None,
+                                want_scores=not lean, want_kp=not lean, want_final=True)
+    if fm["TYPE"] == "Sinkhorn":
+        # the reference's Sinkhorn branch is unreachable through featureMatcher.forward; the maths
+        # restated is feature_matcher.py:125-137 with matching_mat(dsc0, dsc1, None)
+        alpha = W.dustbin if W.dustbin is not None else float(fm["SINKHORN"]["DUSTBIN_SCORE_INIT"])
+        return ops.sinkhorn(dsc0, dsc1, alpha, int(fm["SINKHORN"]["NUM_IT"]), scr0, scr1, want_scores=not lean,
+                            want_kp=not lean, want_final=True)
+    raise ValueError("feature matcher not recognized: %r" % (fm["TYPE"],))
+
+
+def solve(cfg, final_scores, kps0, depth0, kps1, depth1, K0, K1, seed=0, offset=0, noise_outer=None, noise_inner=None,
+          idx3_in=None, debug=False):
+    """reference probabilisticProcrustes.py:183-348 on device.  Returns a dict with R [B,3,3], t [B,1,3],
+    inliers [B,1] and the intermediates needed for the inlier list."""
+    P = cfg["PROCRUSTES"]
+    it_m, it_r, ns, k3 = int(P["IT_MATCHES"]), int(P["IT_RANSAC"]), int(P["NUM_SAMPLED_MATCHES"]), int(P["NUM_CORR_3D_3D"])
+    if k3 != 3:
+        raise ValueError("NUM_CORR_3D_3D must be 3 (the inference solver fits minimal 3-point samples)")
+    B, n0, n1 = final_scores.shape
+    dev = final_scores.device
+    invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
+    idx, cnt = ops.exprace_topk(final_scores.reshape(B, n0 * n1), it_m, ns, noise=noise_outer, seed=seed, offset=offset,
+                                invalid=invalid)
+    X, Y, w, corr = ops.gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, it_m)
+    Rh, th, score, idx3 = ops.ransac_hypotheses(X, Y, w, it_r, float(P["TH_SOFT_INLIER"]), noise3=noise_inner,
+                                                idx3_in=idx3_in, seed=seed, offset=offset + 1)
+    R, t, conf, best, mask, rounds, invalid = ops.refine_pose(X, Y, Rh, th, score, B, it_m, it_r, float(P["TH_INLIER"]),
+                                                              int(P["NUM_REFINEMENTS"]), k3, invalid=invalid)
+    out = {"R": R, "t": t, "inliers": conf, "best": best, "mask": mask, "corr": corr, "weights": w, "invalid": invalid,
+           "it_ransac": it_r, "it_matches": it_m}
+    if debug:
+        out.update(idx=idx, cnt=cnt, X=X, Y=Y, R_hyp=Rh, t_hyp=th, score=score, idx3=idx3, rounds=rounds)
+    return out
+
+
+def inliers_list(sol):
+    """Per pair [m_i, 7] = (u0, v0, u1, v1, score, d0, d1) of the final hard inliers, sorted by score
+    (descending): reference probabilisticProcrustes.py:306-327.  Only built on request (demo 3-D
+    visualisation); a handful of torch index ops on <= 2048 rows per pair, outside the hot path."""
+    B = sol["R"].shape[0]
+    if int(sol["invalid"].item()) != 0:
+        return [torch.zeros([0, 5])] * B
+    k = sol["mask"].shape[1]
+    sets = sol["best"].long() // sol["it_ransac"] + torch.arange(B, device=sol["best"].device) * sol["it_matches"]
+    out = []
+    for b in range(B):
+        sel = sol["mask"][b] != 0
+        c = sol["corr"][sets[b]][sel]
+        w = sol["weights"][sets[b]][sel]
+        order = torch.argsort(w, descending=True)
+        c, w = c[order], w[order]
+        out.append(torch.cat([c[:, 0:4], w[:, None], c[:, 4:6]], 1))
+    return out

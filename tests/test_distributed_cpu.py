@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the sharding + single all-gather of the multi-GPU path (what runs over
+RCCL/xGMI on the GPU node)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeModel:
+    """Stands in for the GPU module: pose = deterministic function of the pair's image mean."""
+
+    def __call__(self, data):
+        B = data["image0"].shape[0]
+        m = data["image0"].reshape(B, -1).mean(1)
+        R = torch.eye(3).repeat(B, 1, 1) * m.view(B, 1, 1)
+        t = torch.stack([m, 2 * m, 3 * m], 1).view(B, 1, 3)
+        data["inliers"] = (10 * m).view(B, 1)
+        data["R"], data["t"] = R, t
+        return R, t
+
+
+def _worker(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mickey_amd import distributed as D
+    g = torch.Generator().manual_seed(0)
+    data = {"image0": torch.rand((B, 3, 4, 4), generator=g), "image1": torch.rand((B, 3, 4, 4), generator=g),
+            "scene_id": ["s%d" % i for i in range(B)], "down": 14}
+    R, t, c, local = D.forward_sharded(_FakeModel(), data, return_local=True)
+    lo, hi = D.shard_range(B, rank, world)
+    ok = local["scene_id"] == data["scene_id"][lo:hi] and local["down"] == 14
+    q.put((rank, R, t, c, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand((B, 3, 4, 4), generator=g)
+    m = img.reshape(B, -1).mean(1)
+    for rank, R, t, c, ok in res:
+        assert ok
+        assert R.shape == (B, 3, 3) and t.shape == (B, 1, 3) and c.shape == (B, 1)
+        assert torch.allclose(R[:, 0, 0], m) and torch.allclose(t[:, 0, 2], 3 * m) and torch.allclose(c[:, 0], 10 * m)
+
+
+def test_even_shards_single_allgather():
+    _run(6)
+
+
+def test_ragged_last_batch():
+    _run(5)
+
+
+def test_shard_range_covers_everything():
+    from mickey_amd.distributed import shard_range
+    for n in (0, 1, 7, 8, 33):
+        for w in (1, 2, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

@@ -1,0 +1,122 @@
+"""CPU (no GPU): host logic and the C-ABI surface -- the library loads and exports every symbol
+include/mickey_hip.h declares, argument validation works without a device, config / checkpoint
+contract, BatchNorm folding, the lib.* drop-in import paths."""
+import copy
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nv():
+    from mickey_amd import build, _native
+    if not os.path.exists(build.lib_path()):
+        build.build(verbose=False)
+    _native.load()
+    return _native
+
+
+def test_abi_exports_every_declared_symbol(nv):
+    hdr = open(os.path.join(ROOT, "include", "mickey_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)   # declarations only
+    declared = set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nv.SIGNATURES), declared ^ set(nv.SIGNATURES)
+    assert nv.missing_symbols() == []
+    assert nv.query("mk_version") >= 100
+    # arity of every binding == arity of the C declaration
+    for name, (_, args) in nv.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), (name, len(params), len(args))
+
+
+def test_abi_rejects_bad_arguments_without_a_device(nv):
+    lib = nv.load()
+    assert lib.mk_gemm(None, 0, None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
+    assert b"gemm" in lib.mk_last_error()
+    assert lib.mk_layernorm(None, 0, None, None, 1e-6, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
+    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12) == 2 * 2 * 4 * 12 * 2
+    assert nv.query("mk_exprace_topk_work_bytes", 1, 20, 2048) > 20 * 8192 * 8
+    with pytest.raises(nv.MickeyHipError):
+        nv.call("mk_flash_attn_fwd", None, None, None, None, 0, 0, 0, 0, 0, 0, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from mickey_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setenv("MICKEY_HIP_LIB", "/nonexistent/libmickey_hip.so")
+    with pytest.raises(_native.MickeyHipError):
+        _native.load()
+
+
+def test_cfg_access_styles(cfg):
+    from mickey_amd.config import as_cfg, CfgDict
+    assert cfg.PROCRUSTES.IT_RANSAC == 100 and cfg["PROCRUSTES"]["IT_MATCHES"] == 20
+    assert cfg.MICKEY.DINOV2.CHANNEL_DIM == 1024 and cfg["FEATURE_MATCHER"]["TYPE"] == "DualSoftmax"
+    # yacs-style schema: None everywhere must not clobber defaults; real overrides win
+    c = as_cfg({"MODEL": "MicKey", "PROCRUSTES": {"IT_RANSAC": 10, "IT_MATCHES": None}, "TRAINING": {"LR": None}})
+    assert c.PROCRUSTES.IT_RANSAC == 10 and c.PROCRUSTES.IT_MATCHES == 20 and isinstance(c.PROCRUSTES, CfgDict)
+    d = copy.deepcopy(c)
+    d.PROCRUSTES.IT_RANSAC = 3
+    assert c.PROCRUSTES.IT_RANSAC == 10
+
+
+def test_bn_fold_matches_basic_block(cfg):
+    """weights.fold_basic_block + a conv == the oracle's conv-BN-ReLU-conv-BN-add block."""
+    from mickey_amd import synthetic as syn, weights
+    from oracle import mickey_oracle as O
+    sd = syn.heads_state_dict(cfg, seed=1)
+    p = "compute_matches.extractor.det_head.resblock3."
+    x = torch.randn((2, 256, 7, 6), generator=torch.Generator().manual_seed(0))
+    ref = O.basic_block(sd, p, x)
+    w1, b1, w2, b2, has_sc = weights.fold_basic_block(sd, p)
+    assert has_sc and w1.shape == (128, 9 * 256) and w2.shape == (128, 9 * 128 + 256)
+    def conv(inp, wflat, cin):
+        w = wflat.reshape(wflat.shape[0], 3, 3, cin).permute(0, 3, 1, 2)
+        return F.conv2d(inp, w, padding=1)
+    h = F.relu(conv(x, w1, 256) + b1.view(1, -1, 1, 1))
+    y = conv(h, w2[:, : 9 * 128], 128) + F.conv2d(x, w2[:, 9 * 128:].reshape(128, 256, 1, 1)) + b2.view(1, -1, 1, 1)
+    assert torch.allclose(F.relu(y), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_checkpoint_contract_and_dropin_imports(cfg, tmp_path):
+    from mickey_amd import synthetic as syn
+    from lib.models.builder import build_model
+    from lib.models.MicKey.compute_pose import MickeyRelativePose
+    from lib.utils.data import data_to_model_device
+    sd = syn.mickey_state_dict(cfg, arch="vit_tiny_test")
+    dino = {k.split("dinov2_vitl14.", 1)[1]: v for k, v in sd.items() if "dinov2_vitl14." in k}
+    mickey_only = {k: v for k, v in sd.items() if "dinov2" not in k}      # what a MicKey .ckpt holds
+    ck = tmp_path / "mickey.ckpt"
+    torch.save({"state_dict": mickey_only, "pytorch-lightning_version": "2.0"}, ck)
+    model = build_model(cfg, str(ck), dinov2_weights=dino)
+    assert isinstance(model, MickeyRelativePose) and not model.training
+    assert set(model.state_dict()) == set(sd)
+    assert model.e2e_Procrustes.num_samples_matches == 2048
+    assert next(model.parameters()).device.type == "cpu"
+    data = data_to_model_device({"image0": torch.zeros(1, 3, 28, 28), "scene_id": ["s"]}, model)
+    assert data["scene_id"] == ["s"]
+    with pytest.raises(RuntimeError):
+        MickeyRelativePose(cfg).load_state_dict(mickey_only)   # no DINOv2 weights anywhere
+    with pytest.raises(NotImplementedError):
+        bad = copy.deepcopy(cfg)
+        bad["MODEL"] = "other"
+        build_model(bad, str(ck))
+
+
+def test_planted_pose_generator_is_consistent():
+    from mickey_amd import synthetic as syn
+    from oracle import mickey_oracle as O
+    data, R, t = syn.planted_pose_problem(B=1, h=20, w=16, seed=3)
+    fs = data["final_scores"][0]
+    i, j = torch.nonzero(fs > 1e-7, as_tuple=True)
+    assert len(i) > 50
+    X = O.backproject(data["kps0"][0, :, i].t()[None], data["depth_kp0"][0, 0, i][None, :, None], data["K_color0"])
+    Y = O.backproject(data["kps1"][0, :, j].t()[None], data["depth_kp1"][0, 0, j][None, :, None], data["K_color1"])
+    assert float(O.point_dist(X, Y, R, t).max()) < 2e-3

@@ -1,0 +1,162 @@
+"""-m gpu: the assembled hot path (encoder + heads + matcher + solver through the C ABI) against the
+reference's own outputs (tests/golden) and against the CPU oracle on the same seeded inputs.
+
+Tolerances: the HIP path computes the encoder and head contractions with 16-bit MFMA operands and fp32
+accumulation (the reference ships an fp16 encoder + fp32 heads); its distance to the fp32 oracle is a
+precision noise floor, not an algorithmic difference.  The floor of the REFERENCE's own fp16 mode on the
+golden case is stored in tests/golden/noise_floor_fp16.npz; bounds below are stated per quantity."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("kps0", "kps1", "depth_kp0", "depth_kp1", "scr0", "scr1", "dsc0", "dsc1", "scores", "kp_scores", "final_scores")
+# rel-Frobenius bounds vs the fp32 reference for 16-bit operands (bf16 has 8 mantissa bits, fp16 11)
+TOL = {
+    torch.bfloat16: dict(kps=2e-4, depth=2e-2, scr=2e-2, dsc=2e-2, scores=4e-2, kp_scores=3e-2, final_scores=5e-2),
+    torch.float16: dict(kps=5e-5, depth=4e-3, scr=6e-3, dsc=5e-3, scores=1e-2, kp_scores=1e-2, final_scores=1.5e-2),
+}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _model(cfg, dtype="bf16", seed=0, **amd):
+    from mickey_amd import synthetic as syn
+    from mickey_amd.model import MickeyRelativePose
+    import copy
+    c = copy.deepcopy(cfg)
+    c["AMD"]["ENCODER_DTYPE"] = dtype
+    c["AMD"].update(amd)
+    sd = syn.mickey_state_dict(c, seed=seed)
+    m = MickeyRelativePose(c)
+    m.load_state_dict(sd)
+    return m.cuda(), sd
+
+
+def test_vit_tiny_encoder_golden(golden):
+    """Encoder kernels alone against the reference's DinoVisionTransformer (tiny arch, 6x9 grid)."""
+    from mickey_amd import pipeline, synthetic as syn, weights
+    dev = _dev()
+    g = golden("vit_tiny")
+    sd = syn.dinov2_state_dict("vit_tiny_test", seed=3)
+    img = torch.rand((2, 3, 84, 126), generator=torch.Generator().manual_seed(11))
+    for dt, tol in ((torch.bfloat16, 1.5e-2), (torch.float16, 2.5e-3)):
+        W = weights.prepare_encoder(sd, dev, dt, prefix="")
+        feat, gh, gw = pipeline.encoder_forward(W, pipeline.Workspace(), img.to(dev))
+        assert (gh, gw) == (6, 9)
+        e = rel(feat.float().reshape(2, 54, 128), g["tokens"])
+        assert e < tol, (dt, e)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_full_forward_golden(golden, cfg, dtype):
+    """ViT-L, 2 pairs of 182x196: every data-dict output against the reference's (fp32) outputs."""
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    g = golden("full_forward")
+    model, _ = _model(cfg, dtype)
+    batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
+    data = {k: v.to(dev) for k, v in batch.items()}
+    R, t = model(data, return_inliers=True)
+    tol = TOL[model.lp_dtype]
+    errs = {k: rel(data[k], g[k]) for k in KEYS}
+    print(dtype, {k: "%.2e" % v for k, v in errs.items()})
+    for k in KEYS:
+        base = k.rstrip("01").replace("depth_kp", "depth")
+        assert errs[k] < tol[base], (k, errs[k])
+    assert float((data["kps0"].cpu() - torch.from_numpy(g["kps0"])).abs().max()) < 0.1   # pixels
+    # contract: shapes / keys the reference's callers read
+    assert R.shape == (2, 3, 3) and t.shape == (2, 1, 3) and data["inliers"].shape == (2, 1)
+    assert data["kps0_shape"] == [13, 14] and data["depth0_map"].shape == (2, 1, 13, 14) and data["down_factor"] == 14
+    assert len(data["inliers_list"]) == 2 and data["inliers_list"][0].shape[1] == 7
+    det = torch.linalg.det(R.double().cpu())
+    assert float((det - 1).abs().max()) < 1e-4
+    # solver on the REFERENCE's final_scores etc. with the oracle's noise == reference pose is covered in
+    # test_solver_gpu.py; here: the pose from the HIP features is a valid rigid transform with a
+    # confidence in the reference's range for this (random-weight, low-signal) case
+    assert torch.isfinite(data["inliers"]).all()
+
+
+def test_full_size_pair_vs_oracle(cfg):
+    """One 720x540 pair (51x38 grid, n = 1938) against the CPU oracle run here on the same seeded
+    weights and inputs (extractor + matcher; ~20 s of CPU)."""
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    from oracle import mickey_oracle as O
+    model, sd = _model(cfg, "bf16")
+    batch = syn.synthetic_batch(B=1, H=720, W=540, seed=1234)
+    data = {k: v.to(dev) for k, v in batch.items()}
+    model.compute_correspondences(data)
+    odata = {k: v.clone() for k, v in batch.items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        odata.update(O.compute_correspondences(sd, cfg, odata))
+    tol = TOL[torch.bfloat16]
+    errs = {k: rel(data[k], odata[k]) for k in KEYS}
+    print("720x540", {k: "%.2e" % v for k, v in errs.items()})
+    for k in KEYS:
+        base = k.rstrip("01").replace("depth_kp", "depth")
+        assert errs[k] < 1.5 * tol[base], (k, errs[k])
+    assert data["scores"].shape == (1, 1938, 1938)
+    # row arg-max of the score matrix: identical wherever the oracle's top-2 gap exceeds the noise floor
+    top2 = odata["scores"].topk(2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.2 * top2[..., 0]
+    agree = (data["scores"].cpu().argmax(2)[clear] == odata["scores"].argmax(2)[clear]).float().mean()
+    assert float(agree) > 0.99, float(agree)
+    # mutual-NN list from the HIP kernel == the oracle's mutual-NN on the same (HIP) scores: bit-exact indices
+    mnn = model.compute_matches.matcher.get_matches_list(data["scores"])
+    ref = O.mutual_nn_matches(data["scores"].cpu())
+    assert torch.equal(mnn.cpu(), ref)
+
+
+def test_forward_determinism_lean_and_shapes(cfg):
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    model, _ = _model(cfg, "bf16")
+    batch = syn.synthetic_batch(B=2, H=196, W=182, seed=5)
+    d1 = {k: v.to(dev) for k, v in batch.items()}
+    d2 = {k: v.to(dev) for k, v in batch.items()}
+    model._calls = 0
+    R1, t1 = model(d1)
+    model._calls = 0
+    R2, t2 = model(d2)
+    assert torch.equal(R1, R2) and torch.equal(t1, t2) and torch.equal(d1["final_scores"], d2["final_scores"])
+    lean, _ = _model(cfg, "bf16", LEAN=True)
+    d3 = {k: v.to(dev) for k, v in batch.items()}
+    lean._calls = 0
+    R3, _ = lean(d3)
+    assert "scores" not in d3 and torch.equal(d3["final_scores"], d1["final_scores"]) and torch.equal(R3, R1)
+    # image pairs of different sizes take the two-pass route
+    d4 = {"image0": batch["image0"].to(dev), "image1": batch["image1"][:, :, :168, :154].contiguous().to(dev),
+          "K_color0": batch["K_color0"].to(dev), "K_color1": batch["K_color1"].to(dev), "scene_id": ["a", "b"]}
+    R4, t4 = model(d4)
+    assert d4["scores"].shape == (2, 14 * 13, 12 * 11) and torch.isfinite(R4).all() and d4["scene_id"] == ["a", "b"]
+    # uncropped input (sizes not multiples of 14) == explicitly cropped input
+    big = torch.rand((1, 3, 190, 200), generator=torch.Generator().manual_seed(1))
+    da = {"image0": big.to(dev), "image1": big.flip(3).contiguous().to(dev), "K_color0": batch["K_color0"][:1].to(dev),
+          "K_color1": batch["K_color1"][:1].to(dev)}
+    db = {"image0": big[:, :, :182, :196].contiguous().to(dev), "image1": big.flip(3)[:, :, :182, :196].contiguous().to(dev),
+          "K_color0": batch["K_color0"][:1].to(dev), "K_color1": batch["K_color1"][:1].to(dev)}
+    model.compute_correspondences(da)
+    model.compute_correspondences(db)
+    assert torch.equal(da["final_scores"], db["final_scores"])
+
+
+def test_cpu_module_raises(cfg):
+    from mickey_amd import synthetic as syn, _native
+    from mickey_amd.model import MickeyRelativePose
+    m = MickeyRelativePose(cfg)
+    m.load_state_dict(syn.mickey_state_dict(cfg, arch="vit_tiny_test"))
+    with pytest.raises(_native.MickeyHipError):
+        m(syn.synthetic_batch(B=1, H=56, W=56))

@@ -1,0 +1,232 @@
+"""-m gpu: the probabilistic-Procrustes solver kernels, stage-isolated against the CPU oracle with the
+random draws INJECTED (SURVEY.md 8(c) parity protocol): sampled indices bit-exact, poses within 1e-4
+Frobenius, plus seed-free statistical checks of the on-device Philox path (planted-pose recovery)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _small_cfg(cfg, it_m=4, it_r=25):
+    c = copy.deepcopy(cfg)
+    c["PROCRUSTES"]["IT_MATCHES"] = it_m
+    c["PROCRUSTES"]["IT_RANSAC"] = it_r
+    return c
+
+
+def _problem(B=3, h=14, w=12, seed=4321):
+    from mickey_amd import synthetic as syn
+    return syn.planted_pose_problem(B=B, h=h, w=w, seed=seed, angle_deg=(1.0, 1.5), t_norm=(0.03, 0.04))
+
+
+def _to(d, dev):
+    return {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def test_sampler_injected_noise_bit_exact():
+    """mk_exprace_topk == torch.topk(p / noise) index for index, order included."""
+    from mickey_amd import ops
+    dev = _dev()
+    data, _, _ = _problem()
+    fs = data["final_scores"]
+    B, n, _ = fs.shape
+    rows = 5
+    noise = torch.empty((B * rows, n * n)).exponential_(1.0, generator=torch.Generator().manual_seed(3))
+    ref = torch.topk(fs.reshape(B, 1, n * n).expand(B, rows, n * n).reshape(B * rows, n * n) / noise, 2048).indices
+    idx, cnt = ops.exprace_topk(fs.reshape(B, n * n).to(dev), rows, 2048, noise=noise.to(dev))
+    assert (cnt.cpu() == 2048).all()
+    assert torch.equal(idx.cpu().long(), ref)
+
+
+def test_sampler_full_size_bit_exact():
+    """Full Map-free size: 2048 of 1938^2 cells x 20 rows, ~45 % zero cells (border-masked scores)."""
+    from mickey_amd import ops
+    dev = _dev()
+    n, rows = 1938, 20
+    g = torch.Generator().manual_seed(9)
+    s0 = torch.rand(n, generator=g) * (torch.rand(n, generator=g) > 0.25)
+    s1 = torch.rand(n, generator=g) * (torch.rand(n, generator=g) > 0.25)
+    fs = (s0[:, None] * s1[None, :] * torch.rand((n, n), generator=g).pow(8) * 1e-7).reshape(1, n * n)
+    noise = torch.empty((rows, n * n)).exponential_(1.0, generator=g)
+    ref = torch.topk(fs.expand(rows, -1) / noise, 2048).indices
+    idx, cnt = ops.exprace_topk(fs.to(dev), rows, 2048, noise=noise.to(dev))
+    assert (cnt.cpu() == 2048).all()
+    assert torch.equal(idx.cpu().long(), ref)
+
+
+def test_sampler_philox_properties():
+    from mickey_amd import ops
+    dev = _dev()
+    data, _, _ = _problem(B=2)
+    fs = data["final_scores"]
+    B, n, _ = fs.shape
+    p = fs.reshape(B, n * n).to(dev)
+    a, ca = ops.exprace_topk(p, 20, 2048, seed=7, offset=1)
+    b, _ = ops.exprace_topk(p, 20, 2048, seed=7, offset=1)
+    c, _ = ops.exprace_topk(p, 20, 2048, seed=7, offset=2)
+    assert torch.equal(a, b), "same (seed, offset) must reproduce the same draw"
+    assert not torch.equal(a, c)
+    a = a.cpu().long()
+    assert (ca.cpu() == 2048).all()
+    for r in range(a.shape[0]):
+        assert a[r].unique().numel() == 2048  # without replacement
+    # planted cells carry ~1000x the background weight: (almost) all of them must be drawn in every row
+    planted = (fs.reshape(B, -1) > 1e-7)
+    for r in range(a.shape[0]):
+        hit = planted[r // 20][a[r]].sum().item()
+        assert hit >= 0.98 * planted[r // 20].sum().item()
+    # keys are sorted in descending order of p/e: a weak consequence is that the first half holds more
+    # planted cells than the second half
+    first = sum(planted[r // 20][a[r, :1024]].sum().item() for r in range(a.shape[0]))
+    second = sum(planted[r // 20][a[r, 1024:]].sum().item() for r in range(a.shape[0]))
+    assert first > second
+
+
+def test_sampler_degenerate_inputs():
+    from mickey_amd import ops
+    dev = _dev()
+    p = torch.zeros((2, 5000))
+    p[0, :100] = 1.0       # fewer positive cells than k
+    p[1, :] = 0.5
+    inv = torch.zeros(1, dtype=torch.int32, device=dev)
+    idx, cnt = ops.exprace_topk(p.to(dev), 3, 2048, seed=1, invalid=inv)
+    assert cnt.cpu().tolist() == [100, 100, 100, 2048, 2048, 2048] and int(inv) == 0
+    assert set(idx[0, :100].cpu().tolist()) == set(range(100))
+    assert idx[0, 100:].cpu().tolist() == list(range(100, 2048))  # zero-probability tail in index order
+    for bad in (float("nan"), float("inf"), -1.0):
+        q = p.clone()
+        q[1, 17] = bad
+        inv.zero_()
+        ops.exprace_topk(q.to(dev), 3, 2048, seed=1, invalid=inv)
+        assert int(inv) == 1
+    inv.zero_()
+    ops.exprace_topk(torch.zeros((1, 5000), device=dev), 3, 2048, seed=1, invalid=inv)
+    assert int(inv) == 1   # sum of probabilities <= 0
+
+
+def test_solver_stages_vs_oracle(cfg):
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    scfg = _small_cfg(cfg)
+    it_m, it_r = 4, 25
+    data, _, _ = _problem()
+    B, n, _ = data["final_scores"].shape
+    torch.manual_seed(5)
+    Ro, to, co, dbg = O.estimate_pose({k: v.clone() for k, v in data.items()}, scfg, return_debug=True)
+    d = _to(data, dev)
+    # (1) gathers + back-projection on the oracle's indices
+    X, Y, w, corr = ops.gather_backproject(dbg["idx"].int().to(dev), d["final_scores"], d["kps0"], d["depth_kp0"], d["kps1"],
+                                           d["depth_kp1"], d["K_color0"], d["K_color1"], it_m)
+    assert torch.allclose(X.cpu(), dbg["X"], rtol=1e-5, atol=1e-6) and torch.allclose(Y.cpu(), dbg["Y"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(w.cpu(), dbg["weights"])
+    # (2) inner sampler with the oracle's noise: indices bit-exact
+    Rh, th, sc, idx3 = ops.ransac_hypotheses(dbg["X"].to(dev), dbg["Y"].to(dev), dbg["weights"].to(dev), it_r, 0.3,
+                                             noise3=dbg["noise_inner"].to(dev))
+    assert torch.equal(idx3.cpu().long(), dbg["idx3"])
+    # (3) hypotheses: R, t within 1e-4 Frobenius on non-degenerate samples, scores within 1e-3
+    S = torch.linalg.svdvals(dbg["H_hyp"].double())
+    ok = (S[:, 1] / S[:, 0]) > 1e-3
+    assert ok.float().mean() > 0.9
+    dR = (Rh.cpu().reshape(-1, 3, 3) - dbg["R_hyp"]).norm(dim=(1, 2))
+    dt = (th.cpu().reshape(-1, 1, 3) - dbg["t_hyp"]).norm(dim=(1, 2))
+    assert float(dR[ok].max()) < 1e-4 and float(dt[ok].max()) < 1e-4, (float(dR[ok].max()), float(dt[ok].max()))
+    det = torch.linalg.det(Rh.cpu().reshape(-1, 3, 3).double())
+    assert torch.isfinite(Rh).all() and float((det - 1).abs().max()) < 1e-5     # also for degenerate samples
+    assert float((sc.cpu()[ok] - dbg["score"].reshape(-1)[ok]).abs().max()) < 1e-3
+    # explicit-index injection gives the same result
+    Rh2, th2, sc2, _ = ops.ransac_hypotheses(dbg["X"].to(dev), dbg["Y"].to(dev), dbg["weights"].to(dev), it_r, 0.3,
+                                             idx3_in=dbg["idx3"].int().to(dev))
+    assert torch.equal(Rh2, Rh) and torch.equal(sc2, sc)
+    # (4) arg-max + refinement on the oracle's hypotheses
+    R, t, conf, best, mask, rounds, inv = ops.refine_pose(
+        dbg["X"].to(dev), dbg["Y"].to(dev), dbg["R_hyp"].reshape(-1, 9).to(dev), dbg["t_hyp"].reshape(-1, 3).to(dev),
+        dbg["score"].reshape(-1).to(dev), B, it_m, it_r, 0.15, 4, 3)
+    assert torch.equal(best.cpu().long(), dbg["best"]) and int(inv) == 0
+    assert float((R.cpu() - Ro).norm(dim=(1, 2)).max()) < 1e-4 and float((t.cpu() - to).norm(dim=(1, 2)).max()) < 1e-4
+    assert torch.allclose(conf.cpu(), co, rtol=1e-3, atol=1e-3)
+    ref_mask = O.hard_inliers(dbg["X_best"], dbg["Y_best"], Ro, to, 0.15)
+    assert (mask.cpu().float() != ref_mask).sum() <= 2    # exact except points on the threshold
+
+
+def test_solver_end_to_end_injected_noise(cfg):
+    from mickey_amd import pipeline
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    scfg = _small_cfg(cfg)
+    data, _, _ = _problem()
+    torch.manual_seed(11)
+    Ro, to, co, inl, dbg = O.estimate_pose({k: v.clone() for k, v in data.items()}, scfg, return_inliers=True,
+                                           return_debug=True)
+    d = _to(data, dev)
+    sol = pipeline.solve(scfg, d["final_scores"], d["kps0"], d["depth_kp0"], d["kps1"], d["depth_kp1"], d["K_color0"],
+                         d["K_color1"], noise_outer=dbg["noise_outer"].to(dev), noise_inner=dbg["noise_inner"].to(dev),
+                         debug=True)
+    assert torch.equal(sol["idx"].cpu().long(), dbg["idx"]) and torch.equal(sol["idx3"].cpu().long(), dbg["idx3"])
+    assert torch.equal(sol["best"].cpu().long(), dbg["best"])
+    assert float((sol["R"].cpu() - Ro).norm(dim=(1, 2)).max()) < 1e-4
+    assert float((sol["t"].cpu() - to).norm(dim=(1, 2)).max()) < 1e-4
+    assert torch.allclose(sol["inliers"].cpu(), co, rtol=1e-3, atol=1e-3)
+    lst = pipeline.inliers_list(sol)
+    for a, b in zip(lst, inl):
+        assert abs(a.shape[0] - b.shape[0]) <= 2 and a.shape[1] == 7
+        if a.shape == b.shape:
+            assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-5)
+
+
+def test_solver_golden(golden, cfg):
+    """Against the REFERENCE's own solver output (tests/golden/solver.npz): its sampled index sets are
+    re-injected, so the pose must match the reference to 1e-4."""
+    from mickey_amd import ops
+    dev = _dev()
+    g = golden("solver")
+    data, _, _ = _problem()
+    d = _to(data, dev)
+    it_m, it_r, B = 4, 25, 3
+    X, Y, w, _ = ops.gather_backproject(torch.from_numpy(g["idx"]).to(dev), d["final_scores"], d["kps0"], d["depth_kp0"],
+                                        d["kps1"], d["depth_kp1"], d["K_color0"], d["K_color1"], it_m)
+    Rh, th, sc, _ = ops.ransac_hypotheses(X, Y, w, it_r, 0.3, idx3_in=torch.from_numpy(g["idx3"]).to(dev))
+    R, t, conf, best, _, _, _ = ops.refine_pose(X, Y, Rh, th, sc, B, it_m, it_r, 0.15, 4, 3)
+    assert torch.equal(best.cpu(), torch.from_numpy(g["best"]))
+    assert float((R.cpu() - torch.from_numpy(g["R"])).norm(dim=(1, 2)).max()) < 1e-4
+    assert float((t.cpu() - torch.from_numpy(g["t"])).norm(dim=(1, 2)).max()) < 1e-4
+    assert torch.allclose(conf.cpu(), torch.from_numpy(g["conf"]), rtol=1e-3, atol=1e-3)
+
+
+def test_planted_pose_recovery_full_size(cfg):
+    """Seed-free check of the Philox path at the Map-free size (51x38 grid, 20x100 hypotheses): the
+    planted pose must be recovered (the reference lands at <= 3e-4 / 1.4e-3 on this family)."""
+    from mickey_amd import pipeline
+    from mickey_amd import synthetic as syn
+    dev = _dev()
+    data, Rgt, tgt = syn.planted_pose_problem(B=3, h=51, w=38, seed=4321)
+    d = _to(data, dev)
+    for off in (0, 10):
+        sol = pipeline.solve(cfg, d["final_scores"], d["kps0"], d["depth_kp0"], d["kps1"], d["depth_kp1"], d["K_color0"],
+                             d["K_color1"], seed=123, offset=off)
+        eR = (sol["R"].cpu() - Rgt).norm(dim=(1, 2))
+        et = (sol["t"].cpu() - tgt).norm(dim=(1, 2))
+        assert float(eR.max()) < 5e-3 and float(et.max()) < 2e-2, (eR, et)
+        assert float(sol["inliers"].min()) > 50
+
+
+def test_zero_pose_on_invalid_matrix(cfg):
+    from mickey_amd import pipeline
+    dev = _dev()
+    scfg = _small_cfg(cfg, 2, 5)
+    data, _, _ = _problem(B=2)
+    d = _to(data, dev)
+    for kind in ("zeros", "nan"):
+        fs = torch.zeros_like(d["final_scores"]) if kind == "zeros" else d["final_scores"].clone()
+        if kind == "nan":
+            fs[1, 3, 3] = float("nan")
+        sol = pipeline.solve(scfg, fs, d["kps0"], d["depth_kp0"], d["kps1"], d["depth_kp1"], d["K_color0"], d["K_color1"])
+        assert float(sol["R"].abs().sum()) == 0 and float(sol["t"].abs().sum()) == 0 and float(sol["inliers"].abs().sum()) == 0
