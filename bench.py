@@ -65,7 +65,7 @@ def cpu_baseline(cfg, sd):
     """The oracle timed on the host cores: 1 pair, full forward, fp32 (bounded sample)."""
     from mickey_amd import synthetic as syn
     from oracle import mickey_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # torch-CPU does not scale past ~32 threads on these ops (256 -> 10x slower)
     torch.set_num_threads(cores)
     data = syn.synthetic_batch(B=1, H=H, W=W, seed=1234)
     t0 = time.time()

@@ -184,6 +184,7 @@ def mutual_nn(scores):
 
 def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None):
     """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
+    p, noise = _c(p, noise)
     _chk(p, torch.float32)
     B, ncell = p.shape
     dev = p.device
@@ -195,7 +196,13 @@ def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None
     return idx, cnt
 
 
+def _c(*ts):
+    """Device pointers are handed to C with implied dense row-major strides: normalise views."""
+    return [None if t is None else t.contiguous() for t in ts]
+
+
 def gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, rows_per_pair):
+    idx, final_scores, kps0, depth0, kps1, depth1, K0, K1 = _c(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1)
     B, n0, n1 = final_scores.shape
     R, k = idx.shape
     dev = idx.device
@@ -209,6 +216,7 @@ def gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, ro
 
 
 def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0):
+    X, Y, wts, noise3, idx3_in = _c(X, Y, wts, noise3, idx3_in)
     nsets, k, _ = X.shape
     dev = X.device
     nh = nsets * it_ransac
@@ -222,6 +230,7 @@ def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, 
 
 
 def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers, invalid=None):
+    X, Y, Rh, th, score = _c(X, Y, Rh, th, score)
     k = X.shape[1]
     dev = X.device
     R = torch.empty((B, 3, 3), device=dev, dtype=torch.float32)
