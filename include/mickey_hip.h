@@ -44,6 +44,10 @@ const char* mk_last_error(void);
 int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldc, int M, int N, int K,
             int act, int out_is_f32, int dtype, mk_stream_t stream);
 
+/* Tile selection of the GEMM/conv kernel: 0 = automatic (by problem size), 1 = force 128x128, 2 = force
+ * 256x256.  Process-wide; for benchmarks and tests. */
+int mk_gemm_set_tile(int mode);
+
 /* `groups` independent GEMMs of identical shape in one launch (element strides per group; a stride
  * of 0 shares the operand).  Used to run the four heads side by side. */
 int mk_gemm_grouped(const void* A, int lda, long long strideA, const void* W, int ldw, long long strideW, const float* bias,

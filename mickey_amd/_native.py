@@ -21,6 +21,7 @@ SIGNATURES = {
     "mk_version": ("i", ""),
     "mk_last_error": ("s", ""),
     "mk_gemm": ("i", "pipippiiiiiiip"),
+    "mk_gemm_set_tile": ("i", "i"),
     "mk_gemm_grouped": ("i", "pilpilplpiliiiiiiip"),
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
     "mk_gemm_qkv": ("i", "pipippppiiiifip"),

@@ -11,8 +11,8 @@
 //     out-of-image taps read a zero page), BatchNorm is folded into W/bias on the host and the
 //     1x1 shortcut conv rides along as extra K columns.
 //
-// Structure (MI355X): 128x128x64 tile, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 via
-// 4x4 v_mfma_f32_16x16x32 fragments.  Operands go HBM -> LDS directly (global_load_lds, 16 B/lane),
+// Structure (MI355X): two instantiations of one body -- 128x128x64 tile / 4 waves (2x2, 64x64 per wave) and
+// 256x256x64 tile / 8 waves (2x4, 128x64 per wave) -- built from v_mfma_f32_16x16x32 fragments.  Operands go HBM -> LDS directly (global_load_lds, 16 B/lane),
 // double-buffered, one barrier per K tile.  The LDS image is lane-linear, so the XOR swizzle that
 // makes the ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address and
 // to the read address (never to the LDS destination).  MFMA operands are swapped (A-operand = W rows,
@@ -25,8 +25,7 @@ namespace {
 
 using namespace mk;
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
 
 enum AMode { A_DENSE = 0, A_CONV3 = 1 };
 
@@ -69,59 +68,55 @@ __device__ __forceinline__ T to_lp(float v) { return (T)v; }
 // owns after the 32x32 S^T MFMA are one contiguous 16-B chunk (see mk_attention.hip)
 __device__ __forceinline__ int vperm(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
-template <typename T, int AMODE>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
-  using V8 = typename Lp<T>::V8;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|W]
+// Per-lane LDS-DMA state of one workgroup tile.  Piece (wave*J + j) is 8 rows x 128 B = 1 KiB of the LDS image; this
+// lane feeds row +(lane>>3), 16-byte chunk lane&7 of it, fetching the XOR-swizzled source chunk.
+template <typename T, int AMODE, int NW, int AJ, int WJ>
+struct Stager {
+  const T* A;
+  const T* A2;
+  const T* wrow[WJ];
+  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: pixel index of the row
+  int ay[AJ], ax[AJ];
+  bool avalid[AJ];
+  int wave, srow, sp;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g = blockIdx.y;
-
-  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  const int id = xcd_remap(blockIdx.x, ntm * ntn);
-  const int tile_m = id / ntn, tile_n = id % ntn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const T* A = (const T*)p.A + (long long)g * p.strideA_g;
-  const T* A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
-  const T* W = (const T*)p.W + (long long)g * p.strideW_g;
-
-  // ---- per-lane staging state: this lane feeds rows wave*32 + j*8 + (lane>>3), chunk lane&7 ----
-  const int srow = lane >> 3, sp = lane & 7;
-  const T* wrow[4];
-  long long aoff[4];  // dense: element offset of (row, swizzled chunk); conv: pixel index of the row
-  int ay[4], ax[4];
-  bool avalid[4];
+  __device__ __forceinline__ void init(const GemmParams& p, int g, int m0, int n0, int wave_, int lane) {
+    wave = wave_;
+    srow = lane >> 3;
+    sp = lane & 7;
+    A = (const T*)p.A + (long long)g * p.strideA_g;
+    A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+    const T* W = (const T*)p.W + (long long)g * p.strideW_g;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = wave * 32 + j * 8 + srow;
-    int n = n0 + r;
-    n = n < p.N ? n : p.N - 1;
-    wrow[j] = W + (long long)n * p.ldw + swz8(r, sp) * 8;
-    int m = m0 + r;
-    avalid[j] = m < p.M;
-    m = avalid[j] ? m : p.M - 1;
-    if (AMODE == A_DENSE) {
-      aoff[j] = (long long)m * p.lda + swz8(r, sp) * 8;
-      ay[j] = ax[j] = 0;
-    } else {
-      const int pix = m % (p.H * p.Wd);
-      ay[j] = pix / p.Wd;
-      ax[j] = pix % p.Wd;
-      aoff[j] = m;
+    for (int j = 0; j < WJ; ++j) {
+      const int r = (wave * WJ + j) * 8 + srow;
+      int n = n0 + r;
+      n = n < p.N ? n : p.N - 1;
+      wrow[j] = W + (long long)n * p.ldw + swz8(r, sp) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int r = (wave * AJ + j) * 8 + srow;
+      int m = m0 + r;
+      avalid[j] = m < p.M;
+      m = avalid[j] ? m : p.M - 1;
+      if (AMODE == A_DENSE) {
+        aoff[j] = (long long)m * p.lda + swz8(r, sp) * 8;
+        ay[j] = ax[j] = 0;
+      } else {
+        const int pix = m % (p.H * p.Wd);
+        ay[j] = pix / p.Wd;
+        ax[j] = pix % p.Wd;
+        aoff[j] = m;
+      }
     }
   }
 
-  auto stage = [&](int buf, int kt) {
-    char* sA = smem + buf * 2 * TILE_BYTES;
-    char* sW = sA + TILE_BYTES;
+  __device__ __forceinline__ void issue(const GemmParams& p, char* sA, char* sW, int kt) const {
     const int k0 = kt * BK;
     if (AMODE == A_DENSE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) glds16(A + aoff[j] + k0, sA + (wave * 32 + j * 8) * 128);
+      for (int j = 0; j < AJ; ++j) glds16(A + aoff[j] + k0, sA + (wave * AJ + j) * 1024);
     } else {
       // wave-uniform: which source / tap does this K tile belong to
       const int kc = 9 * p.C1;
@@ -141,56 +136,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
         cs = p.C2;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wave * 32 + j * 8 + srow;
-        const long long pixm = aoff[j];
+      for (int j = 0; j < AJ; ++j) {
+        const int r = (wave * AJ + j) * 8 + srow;
         const int yy = ay[j] + dy, xx = ax[j] + dx;
         const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-        const T* s = ok ? src + (pixm + dy * p.Wd + dx) * cs + c0 + swz8(r, sp) * 8 : (const T*)p.zero_page + sp * 8;
-        glds16(s, sA + (wave * 32 + j * 8) * 128);
+        const T* s = ok ? src + (aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(r, sp) * 8 : (const T*)p.zero_page + sp * 8;
+        glds16(s, sA + (wave * AJ + j) * 1024);
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(wrow[j] + k0, sW + (wave * 32 + j * 8) * 128);
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* sA = smem + (kt & 1) * 2 * TILE_BYTES;
-    const char* sW = sA + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V8 wf[4], xf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rw = wn * 64 + i * 16 + fr;
-        wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
-        const int rx = wm * 64 + i * 16 + fr;
-        xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
-    }
+    for (int j = 0; j < WJ; ++j) glds16(wrow[j] + k0, sW + (wave * WJ + j) * 1024);
   }
+};
 
-  // ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
+// ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
+template <typename T, int WMF>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
+                                         int g) {
+  const int fr = lane & 15, fg = lane >> 4;
   const float* bias = p.bias ? p.bias + (long long)g * p.strideBias_g : nullptr;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + fr;
+  for (int mi = 0; mi < WMF; ++mi) {
+    const int m = m0 + wm * (WMF * 16) + mi * 16 + fr;
     if (m >= p.M) continue;
     int img = 0, tok = 0;
     if (p.epi == MK_EPI_QKV) {
@@ -268,16 +235,299 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <int AMODE>
-int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
+// WMF = 16-row M fragments per wave (4 -> 64 rows, 8 -> 128 rows); waves in an NWM x NWN grid, each wave 64 columns.
+//   <4,2,2>: 128x128 tile, 256 threads, 64 KiB LDS  (2 workgroups / CU)  -- small / skinny problems
+//   <8,2,4>: 256x256 tile, 512 threads, 128 KiB LDS (1 workgroup / CU)
+// Two LDS stages, the LDS-DMA of K tile kt+1 is issued before the MFMAs of tile kt, one barrier per K tile.
+template <typename T, int AMODE, int WMF, int NWM, int NWN>
+__global__ __launch_bounds__(NWM* NWN * 64, (NWM * NWN) / 4) void gemm_kernel(GemmParams p) {
+  using V8 = typename Lp<T>::V8;
+  constexpr int NW = NWM * NWN, BM = NWM * WMF * 16, BN = NWN * 64;
+  constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;          // 1-KiB LDS-DMA pieces per wave per K tile
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile], rows of 128 B
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int g = blockIdx.y;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, groups, 1);
-  if (dtype == MK_BF16)
-    hipLaunchKernelGGL((gemm_kernel<__bf16, AMODE>), grid, dim3(NTHREADS), 0, st, p);
-  else
-    hipLaunchKernelGGL((gemm_kernel<_Float16, AMODE>), grid, dim3(NTHREADS), 0, st, p);
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  Stager<T, AMODE, NW, AJ, WJ> st;
+  st.init(p, g, m0, n0, wave, lane);
+
+  f32x4 acc[WMF][4];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  st.issue(p, smem, smem + A_BYTES, 0);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) st.issue(p, smem + ((kt + 1) & 1) * STAGE_BYTES, smem + ((kt + 1) & 1) * STAGE_BYTES + A_BYTES, kt + 1);
+    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      V8 wf[4], xf[WMF];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rw = wn * 64 + i * 16 + fr;
+        wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < WMF; ++i) {
+        const int rx = wm * (WMF * 16) + i * 16 + fr;
+        xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < WMF; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+    }
+  }
+  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// "Ping-pong" 256x256 kernel: 8 waves = 2 wave-rows x 4, 128x64 outputs per wave, K tiles of 32, 4-deep LDS ring.
+// The two wave-rows -- whose waves share SIMDs pairwise (w, w+4) -- run half a K tile apart: in every
+// barrier-delimited slot one wave-row executes its 32 MFMAs of a K tile from REGISTERS (its 12 fragments were
+// preloaded in the previous slot) while the other one issues LDS-DMA and reads its fragments, so each SIMD's matrix
+// pipe is fed by one wave while its partner does the memory work (s_setprio favours the MFMA wave).
+//   even slot 2kt  : wait(stage kt landed: counted vmcnt), barrier | row0: read frags(kt)        | row1: MFMA(kt-1) + DMA(kt+3)
+//   odd  slot 2kt+1: barrier                                       | row0: MFMA(kt) + DMA(kt+3)  | row1: read frags(kt)
+// Each wave issues its own 4 LDS-DMA pieces of a tile inside its MFMA slot (in the MFMA shadow), into the ring slot of
+// a tile whose last reader is at least one barrier behind; a DMA has >= 4 slots to land.  Barriers are bare
+// s_barrier: nothing ever drains the DMA queue to zero inside the loop.
+constexpr int PK = 32;          // K tile of the ping-pong kernel
+constexpr int PSTAGES = 4;
+
+// 64-byte LDS rows (4 chunks of 16 B): chunk' = chunk ^ ((-(row >> 2)) & 3) is conflict-free for ds_read_b128
+__device__ __forceinline__ int swz4(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
+
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+  using V8 = typename Lp<T>::V8;
+  constexpr int WMF = 8, NWN = 4, BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * 64, STAGE_BYTES = (BM + BN) * 64;   // 32 KiB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;   // wm = wave-row = ping-pong group
+  const int g = blockIdx.y;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  // ---- LDS-DMA state: piece = 16 rows x 64 B; this wave owns pieces 2*wave, 2*wave+1 of A and of W ----
+  const T* A = (const T*)p.A + (long long)g * p.strideA_g;
+  const T* A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+  const T* W = (const T*)p.W + (long long)g * p.strideW_g;
+  const int srow = lane >> 2, sp = lane & 3;
+  const T* wrow[2];
+  long long aoff[2];
+  int ay[2], ax[2];
+  bool avalid[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 16 + srow;
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    wrow[j] = W + (long long)n * p.ldw + swz4(r, sp) * 8;
+    int m = m0 + r;
+    avalid[j] = m < p.M;
+    m = avalid[j] ? m : p.M - 1;
+    if (AMODE == A_DENSE) {
+      aoff[j] = (long long)m * p.lda + swz4(r, sp) * 8;
+      ay[j] = ax[j] = 0;
+    } else {
+      const int pix = m % (p.H * p.Wd);
+      ay[j] = pix / p.Wd;
+      ax[j] = pix % p.Wd;
+      aoff[j] = m;
+    }
+  }
+  // one LDS-DMA instruction: piece q of K tile kt (q = 0,1: A pieces; 2,3: W pieces).  Every wave issues exactly
+  // these 4 per K tile, in this order (the vmcnt arithmetic relies on it)
+  auto issue_piece = [&](int kt, int q) {
+    char* sA = smem + (kt % PSTAGES) * STAGE_BYTES;
+    char* sW = sA + A_BYTES;
+    const int k0 = kt * PK;
+    if (q >= 2) {
+      glds16(wrow[q - 2] + k0, sW + (wave * 2 + (q - 2)) * 1024);
+    } else if (AMODE == A_DENSE) {
+      glds16(A + aoff[q] + k0, sA + (wave * 2 + q) * 1024);
+    } else {
+      const int kc = 9 * p.C1;
+      const T* src;
+      int cs, c0, dy, dx;
+      if (k0 < kc) {
+        const int tap = k0 / p.C1;
+        c0 = k0 - tap * p.C1;
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+        src = A;
+        cs = p.C1;
+      } else {
+        c0 = k0 - kc;
+        dy = dx = 0;
+        src = A2;
+        cs = p.C2;
+      }
+      const int r = (wave * 2 + q) * 16 + srow;
+      const int yy = ay[q] + dy, xx = ax[q] + dx;
+      const bool ok = avalid[q] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+      const T* s = ok ? src + (aoff[q] + dy * p.Wd + dx) * cs + c0 + swz4(r, sp) * 8 : (const T*)p.zero_page + sp * 8;
+      glds16(s, sA + (wave * 2 + q) * 1024);
+    }
+  };
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece(kt, q);
+  };
+
+  f32x4 acc[WMF][4];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V8 wf[4], xf[WMF];
+
+  const int fr = lane & 15, fg = lane >> 4;
+  auto load_frags = [&](int kt) {
+    const char* sA = smem + (kt % PSTAGES) * STAGE_BYTES;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rw = wn * 64 + i * 16 + fr;
+      wf[i] = *(const V8*)(sW + rw * 64 + swz4(rw, fg) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WMF; ++i) {
+      const int rx = wm * (WMF * 16) + i * 16 + fr;
+      xf[i] = *(const V8*)(sA + rx * 64 + swz4(rx, fg) * 16);
+    }
+  };
+  const int nk = p.K / PK;
+  // 32 MFMAs from registers; the 4 LDS-DMA instructions of K tile `kt_dma` (if < nk) ride in the MFMA shadow
+  auto mfma_tile = [&](int kt_dma) {
+    const bool dma = kt_dma < nk;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < WMF; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+      if ((mi & 1) && dma) issue_piece(kt_dma, mi >> 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  if (wm == 1 && nk > 3) issue(3);   // wave-row 1 idles in slot 0: it pre-issues its share of tile 3
+  // even-slot entry: this wave's LDS-DMA of tile kt has landed once at most the 4 * (tiles issued after kt) newest
+  // DMAs are outstanding (both wave-rows have issued up to tile kt+2 at that point); the barrier then makes every
+  // wave's share of tile kt visible
+  auto even_entry = [&](int kt) {
+    const int newer = nk - 1 - kt;
+    if (newer >= 2)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (newer == 1)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto odd_entry = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // the two wave-rows run separate straight-line loops (same number of barriers per K tile), so the accumulators
+  // never flow through a conditional merge
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      even_entry(kt);
+      load_frags(kt);
+      odd_entry();
+      mfma_tile(kt + 3);   // slot 2kt+1: ring slot (kt+3)%4 was last read in slot 2kt-1
+    }
+  } else {
+    // same barrier sequence, loop boundary shifted by one slot so that fragments are loaded and consumed inside
+    // one iteration (no loop-carried fragment registers)
+    even_entry(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      odd_entry();
+      load_frags(kt);
+      if (kt + 1 < nk) even_entry(kt + 1);
+      mfma_tile(kt + 4);   // slot 2kt+2: ring slot kt%4 was last read in slot 2kt+1 (by this wave-row)
+    }
+  }
+  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+}
+
+template <typename T, int AMODE, int WMF, int NWM, int NWN>
+int launch_cfg(const GemmParams& p, int groups, hipStream_t st) {
+  constexpr int BM = NWM * WMF * 16, BN = NWN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_done = false;  // benign race: the attribute call is idempotent
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, NWM, NWN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MK_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, NWM, NWN>), dim3(ntm * ntn, groups, 1), dim3(NWM * NWN * 64), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
+}
+
+template <typename T, int AMODE>
+int launch_pp(const GemmParams& p, int groups, hipStream_t st) {
+  constexpr int LDS = PSTAGES * 512 * 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MK_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_pp_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int g_force_tile = 0;  // 0 auto, 1 force 128x128, 2 force 256x256, 3 force 256x256 ping-pong (mk_gemm_set_tile)
+
+template <int AMODE>
+int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
+  // 256x256 tiles need enough of them to fill 256 CUs (1 workgroup per CU); otherwise 128x128 (2 per CU)
+  const long long big_tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * groups;
+  bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
+  if (g_force_tile == 1) big = false;
+  if (g_force_tile == 2) big = true;
+  if (g_force_tile == 3)
+    return dtype == MK_BF16 ? launch_pp<__bf16, AMODE>(p, groups, st) : launch_pp<_Float16, AMODE>(p, groups, st);
+  if (dtype == MK_BF16)
+    return big ? launch_cfg<__bf16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<__bf16, AMODE, 4, 2, 2>(p, groups, st);
+  return big ? launch_cfg<_Float16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<_Float16, AMODE, 4, 2, 2>(p, groups, st);
 }
 
 int check_common(const GemmParams& p, int dtype) {
@@ -293,6 +543,12 @@ int check_common(const GemmParams& p, int dtype) {
 }  // namespace
 
 extern "C" {
+
+int mk_gemm_set_tile(int mode) {
+  MK_CHECK_ARG(mode >= 0 && mode <= 3, "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
+  g_force_tile = mode;
+  return MK_OK;
+}
 
 int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldc, int M, int N, int K,
             int act, int out_is_f32, int dtype, mk_stream_t stream) {

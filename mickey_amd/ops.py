@@ -18,6 +18,11 @@ def _chk(t, dtype=None):
     return t
 
 
+def gemm_set_tile(mode):
+    """0 auto, 1 force the 128x128 tile, 2 force the 256x256 tile (tests / benchmarks)."""
+    call("mk_gemm_set_tile", int(mode))
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, out_f32=False, out=None, lda=None, K=None):
     """out = act(a[:, :K] @ w[:, :K].T + bias).  a [M, lda] lp, w [N, ldw] lp."""
     M = a.shape[0]

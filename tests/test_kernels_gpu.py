@@ -25,11 +25,21 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+@pytest.fixture(autouse=True)
+def _auto_tile():
+    yield
+    if torch.cuda.is_available():
+        from mickey_amd import ops
+        ops.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64)])
-def test_gemm_bias_act(dtype, M, N, K):
+def test_gemm_bias_act(dtype, M, N, K, tile):
     from mickey_amd import ops
     dev = _dev()
+    ops.gemm_set_tile(tile)
     a = (torch.randn((M, K), generator=g(1)) * 0.5).to(dtype)
     w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).to(dtype)
     bias = torch.randn((N,), generator=g(3))
@@ -61,9 +71,11 @@ def test_gemm_ls_residual():
     assert rel(xd, ref) < 1e-5
 
 
-def test_gemm_qkv_layout():
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_qkv_layout(tile):
     from mickey_amd import ops
     dev = _dev()
+    ops.gemm_set_tile(tile)
     nimg, ntok, heads = 2, 333, 4
     D, pad = heads * 64, 384
     a = (torch.randn((nimg * ntok, D), generator=g(1)) * 0.5).bfloat16()
@@ -156,10 +168,12 @@ def test_flash_attention(dtype, ntok):
     assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("with_sc,with_res", [(False, False), (True, False), (False, True)])
-def test_conv3x3(with_sc, with_res):
+def test_conv3x3(with_sc, with_res, tile):
     from mickey_amd import ops
     dev = _dev()
+    ops.gemm_set_tile(tile)
     G, nimg, H, W, C1, C2, Cout = 3, 2, 9, 7, 128, 64, 128 if with_res else 192
     if with_res:
         Cout = C1

@@ -32,15 +32,18 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     res = []
-    for M in (3878, 3878 * 8):
+    for M in (3878, 3878 * 8, 3878 * 32):
         for (N, K, name) in ((3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc1"), (1024, 4096, "fc2")):
             a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
             w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
             out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-            t = timeit(lambda: ops.gemm(a, w, None, out=out))
-            tf = 2.0 * M * N * K / t / 1e12
-            res.append({"kernel": "gemm_" + name, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf})
-            print(res[-1], flush=True)
+            for tile in (1, 2, 3):
+                ops.gemm_set_tile(tile)
+                t = timeit(lambda: ops.gemm(a, w, None, out=out))
+                tf = 2.0 * M * N * K / t / 1e12
+                res.append({"kernel": "gemm_" + name, "tile": tile, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf})
+                print(res[-1], flush=True)
+            ops.gemm_set_tile(0)
     for nimg in (2, 16):
         heads, ntok, pad = 16, 1939, 1984
         q = (torch.randn((nimg, heads, pad, 64), device=dev) * 0.2).bfloat16()
