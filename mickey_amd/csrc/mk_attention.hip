@@ -3,7 +3,7 @@
 // path :72-76 is the same maths).  The ntok x ntok score matrix never leaves registers.
 //
 // Design (wave64, v_mfma_f32_32x32x16):
-//  * workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 queries.
+//  * workgroup = 4 waves of one (image, head); each wave owns 32 or 64 queries (QB sub-blocks of 32).
 //  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
 //    (lane-linear image; XOR swizzle on the source address + on the ds_read_b128), double-buffered.
 //  * S^T = K.Q^T ("swapped" product): after the MFMA a lane holds 32 scores of ONE query, so the
@@ -19,7 +19,9 @@ using namespace mk;
 
 constexpr int KV_TILE_BYTES = 64 * 64 * 2;  // 8 KiB
 
-template <typename T>
+// QB = 32-query sub-blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs
+// and a workgroup covers 256 queries per staged K/V tile (half the LDS-DMA, ds_read and barrier work per MFMA).
+template <typename T, int QB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ vt, T* __restrict__ out, int ldo, int heads,
                                                           int ntok, int ntok_pad) {
@@ -34,14 +36,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   const T* Qh = q + hb * ntok_pad * 64;
   const T* Kh = k + hb * ntok_pad * 64;
   const T* Vh = vt + hb * 64 * ntok_pad;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
   const int j = lane & 31, hi = lane >> 5;
 
-  int qrow = q0 + j;
-  qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
-  V8 qf[4];
+  V8 qf[QB][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  for (int qb = 0; qb < QB; ++qb) {
+    int qrow = q0 + qb * 32 + j;
+    qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  }
 
   const int srow = lane >> 3, sp = lane & 7;
   auto stage = [&](int buf, int kt) {
@@ -56,10 +61,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     }
   };
 
-  f32x16 o[2];
+  f32x16 o[QB][2];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[qb][0][i] = o[qb][1][i] = 0.f;
+    m_run[qb] = -1e30f;
+    l_run[qb] = 0.f;
+  }
 
   const int nkt = (ntok + 63) >> 6;
   stage(0, 0);
@@ -70,80 +80,109 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
 
-    f32x16 s[2];
+    f32x16 s[QB][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
       const int row = kb * 32 + j;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 2 + hi) * 16);
-        s[kb] = Lp<T>::mma32(kf, qf[ks], s[kb]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = Lp<T>::mma32(kf, qf[qb][ks], s[qb][kb]);
       }
     }
-    if (kt == nkt - 1 && (ntok & 63)) {
+    V8 pf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (kt == nkt - 1 && (ntok & 63)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= ntok) s[qb][kb][r] = -1e30f;
+          }
+      }
+      float mx = s[qb][0][0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[qb][0][r], s[qb][1][r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // raw v_exp_f32 (exp2f() would add ~5 range-fixup instructions per element; arguments here are <= 0 and
+      // results below the normal range may flush to zero, which is what a softmax tail wants anyway)
+      const float m_new = fmaxf(m_run[qb], mx);
+      const bool grew = m_new > m_run[qb];
+      float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= ntok) s[kb][r] = -1e30f;
+          const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
+          s[qb][kb][r] = pv;
+          rs += pv;
         }
-    }
-    float mx = s[0][0];
+      if (__any(grew)) {   // wave-uniform: after the first tiles the running max rarely moves -> no O rescale
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        l_run[qb] *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float rs = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[kb][r] - m_new);
-        s[kb][r] = pv;
-        rs += pv;
+        for (int i = 0; i < 16; ++i) {
+          o[qb][0][i] *= alpha;
+          o[qb][1][i] *= alpha;
+        }
       }
-    l_run = l_run * alpha + rs;
+      m_run[qb] = m_new;
+      l_run[qb] += rs;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      o[0][i] *= alpha;
-      o[1][i] *= alpha;
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[qb][s4][e] = (T)s[qb][s4 >> 1][(s4 & 1) * 8 + e];
     }
-    V8 pf[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)s[s4 >> 1][(s4 & 1) * 8 + e];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int row = dt * 32 + j;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
-        o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[qb][dt] = Lp<T>::mma32(vf, pf[qb][s4], o[qb][dt]);
       }
     }
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int qi = q0 + j;
-  if (qi < ntok) {
-    T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + qb * 32 + j;
+    if (qi < ntok) {
+      T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        V4 w;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][r4 * 4 + e] * inv);
-        *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
-      }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          V4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (T)(o[qb][dt][r4 * 4 + e] * inv);
+          *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+        }
+    }
   }
+}
+
+template <typename T>
+void launch_attn(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads, int ntok, int ntok_pad,
+                 hipStream_t st) {
+  // 64 queries per wave once that still leaves >= 2 workgroups per CU; 32 queries per wave for small batches
+  const long long blocks2 = (long long)((ntok + 255) / 256) * heads * nimg;
+  if (blocks2 >= 512)
+    hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
 }
 
 }  // namespace
@@ -154,13 +193,10 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, v
   MK_CHECK_ARG(nimg > 0 && heads > 0 && ntok > 0 && ntok_pad % 64 == 0 && ntok_pad >= ntok && ldo % 4 == 0 &&
                    ldo >= heads * 64,
                "mk_flash_attn_fwd: bad geometry");
-  dim3 grid((ntok + 127) / 128, heads, nimg);
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)vt, (__bf16*)out, ldo, heads, ntok, ntok_pad);
+    launch_attn<__bf16>(q, k, vt, out, ldo, nimg, heads, ntok, ntok_pad, (hipStream_t)stream);
   else if (dtype == MK_F16)
-    hipLaunchKernelGGL(attn_fwd_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)q,
-                       (const _Float16*)k, (const _Float16*)vt, (_Float16*)out, ldo, heads, ntok, ntok_pad);
+    launch_attn<_Float16>(q, k, vt, out, ldo, nimg, heads, ntok, ntok_pad, (hipStream_t)stream);
   else
     MK_CHECK_ARG(false, "mk_flash_attn_fwd: bad dtype");
   MK_CHECK_LAUNCH();

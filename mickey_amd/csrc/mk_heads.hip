@@ -34,29 +34,37 @@ __global__ __launch_bounds__(256) void posenc_kernel(const T* __restrict__ x, co
 
 __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.0f : expf(x); }  // elu(x) + 1
 
-// partial KV over a chunk of tokens: thread (d = t>>4, v = t&15)
+// partial KV over a chunk of tokens for ALL heads of one (group, image): thread = (head, d, half of v); whole
+// 3C-wide rows are read coalesced (k as scalars, v as 2 x float4)
 __global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restrict__ qkv, float* __restrict__ part, int L, int C,
                                                           int nchunk) {
   const int H = C >> 4;
-  const int gih = blockIdx.y;           // (g*nimg + img)*H + h
-  const int h = gih % H;
-  const long long gi = gih / H;         // g*nimg + img
+  const long long gi = blockIdx.y;      // g*nimg + img
   const int chunk = blockIdx.x;
-  const int d = threadIdx.x >> 4, v = threadIdx.x & 15;
+  const int t = threadIdx.x;
+  const int h = t >> 5, d = (t >> 1) & 15, vh = t & 1;
+  if (h >= H) return;
   const int s0 = chunk * KV_CHUNK, s1 = min(L, s0 + KV_CHUNK);
   const float invL = 1.0f / (float)L;
   const float* base = qkv + gi * (long long)L * 3 * C;
-  float acc = 0.f, ks = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float ks = 0.f;
   for (int s = s0; s < s1; ++s) {
     const float* row = base + (long long)s * 3 * C;
     const float kd = phi(row[C + h * 16 + d]);
-    const float vv = row[2 * C + h * 16 + v] * invL;
-    acc += kd * vv;
+    const f32x4 v0 = *(const f32x4*)(row + 2 * C + h * 16 + vh * 8);
+    const f32x4 v1 = *(const f32x4*)(row + 2 * C + h * 16 + vh * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[e] += kd * (v0[e] * invL);
+      acc[4 + e] += kd * (v1[e] * invL);
+    }
     ks += kd;
   }
-  float* o = part + ((long long)gih * nchunk + chunk) * KVW;
-  o[d * 16 + v] = acc;
-  if (v == 0) o[256 + d] = ks;
+  float* o = part + (((gi * H + h) * nchunk) + chunk) * KVW;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[d * 16 + vh * 8 + e] = acc[e];
+  if (vh == 0) o[256 + d] = ks;
 }
 
 __global__ __launch_bounds__(KVW) void linattn_kv_reduce(const float* __restrict__ part, float* __restrict__ kv, int nchunk) {
@@ -241,10 +249,11 @@ long long mk_linattn_work_floats(int groups, int nimg, int L, int C) {
 }
 
 int mk_linattn_kv(const float* qkv, float* kv, float* work, int groups, int nimg, int L, int C, mk_stream_t stream) {
-  MK_CHECK_ARG(qkv && kv && work && groups > 0 && nimg > 0 && L > 0 && C % 16 == 0, "mk_linattn_kv: bad args");
+  MK_CHECK_ARG(qkv && kv && work && groups > 0 && nimg > 0 && L > 0 && C % 16 == 0 && C <= 128, "mk_linattn_kv: bad args (C <= 128)");
   const int nchunk = (L + KV_CHUNK - 1) / KV_CHUNK;
   const int gih = groups * nimg * (C / 16);
-  hipLaunchKernelGGL(linattn_kv_partial, dim3(nchunk, gih), dim3(256), 0, (hipStream_t)stream, qkv, work, L, C, nchunk);
+  hipLaunchKernelGGL(linattn_kv_partial, dim3(nchunk, groups * nimg), dim3(256), 0, (hipStream_t)stream, qkv, work, L, C,
+                     nchunk);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(linattn_kv_reduce, dim3(gih), dim3(KVW), 0, (hipStream_t)stream, work, kv, nchunk);
   MK_CHECK_LAUNCH();

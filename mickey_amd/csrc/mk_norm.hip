@@ -11,66 +11,82 @@ using namespace mk;
 
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 
+constexpr int LN_RPW = 4;   // rows per wave: the loads of row r+1 are in flight while row r is reduced and stored
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
                                                         int rows_per_img, int skip, int wgroup_rows) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows_out) return;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+  if (r0 >= rows_out) return;
   const int rpo = rows_per_img - skip;
-  const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
-  const float* xr = x + rin * ldx;
-  if (wgroup_rows > 0) {  // one (w, b) per block of wgroup_rows output rows
-    w += (long long)(r / wgroup_rows) * D;
-    b += (long long)(r / wgroup_rows) * D;
-  }
-  f32x4 v[LN_MAXV];
-  float s = 0.f;
+  f32x4 v[2][LN_MAXV];
+  auto load_row = [&](int r, f32x4 (&dst)[LN_MAXV]) {
+    const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
+    const float* xr = x + rin * ldx;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < D) {
-      v[i] = *(const f32x4*)(xr + c);
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) dst[i] = *(const f32x4*)(xr + c);
     }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
+  };
+  load_row(r0, v[0]);
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < D) {
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    const int r = r0 + rr;
+    if (r >= rows_out) break;
+    if (rr + 1 < LN_RPW && r + 1 < rows_out) load_row(r + 1, v[(rr + 1) & 1]);
+    f32x4 (&cur)[LN_MAXV] = v[rr & 1];
+    const float* wr = w;
+    const float* br = b;
+    if (wgroup_rows > 0) {  // one (w, b) per block of wgroup_rows output rows
+      wr += (long long)(r / wgroup_rows) * D;
+      br += (long long)(r / wgroup_rows) * D;
+    }
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = v[i][e] - mean;
-        q += d * d;
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) s += (cur[i][0] + cur[i][1]) + (cur[i][2] + cur[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = cur[i][e] - mean;
+          q += d * d;
+        }
       }
     }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < D) {
-      const f32x4 ww = *(const f32x4*)(w + c), bb = *(const f32x4*)(b + c);
-      f32x4 y;
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const f32x4 ww = *(const f32x4*)(wr + c), bb = *(const f32x4*)(br + c);
+        f32x4 y;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
-      if (resid) {
-        float* rp = resid + (long long)r * ldr + c;
-        y += *(const f32x4*)rp;
-        *(f32x4*)rp = y;
-      }
-      if (out) {
-        if (out_is_f32) {
-          *(f32x4*)((float*)out + (long long)r * ldo + c) = y;
-        } else {
-          typename Lp<T>::V4 o;
+        for (int e = 0; e < 4; ++e) y[e] = (cur[i][e] - mean) * rstd * ww[e] + bb[e];
+        if (resid) {
+          float* rp = resid + (long long)r * ldr + c;
+          y += *(const f32x4*)rp;
+          *(f32x4*)rp = y;
+        }
+        if (out) {
+          if (out_is_f32) {
+            *(f32x4*)((float*)out + (long long)r * ldo + c) = y;
+          } else {
+            typename Lp<T>::V4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
-          *(typename Lp<T>::V4*)((T*)out + (long long)r * ldo + c) = o;
+            for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
+            *(typename Lp<T>::V4*)((T*)out + (long long)r * ldo + c) = o;
+          }
         }
       }
     }
@@ -137,7 +153,7 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                LN_MAXV * 256);
   MK_CHECK_ARG(rows_out > 0 && rows_per_img > skip && skip >= 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
                "mk_layernorm: bad geometry");
-  dim3 grid((rows_out + 3) / 4);
+  dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
   if (dtype == MK_BF16)
     hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
                        out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows);

@@ -142,11 +142,11 @@ def test_layernorm(D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("ntok", [64, 200, 1939])
-def test_flash_attention(dtype, ntok):
+@pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])
+def test_flash_attention(dtype, ntok, nimg, heads):
+    """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the 64-queries-per-wave instantiation."""
     from mickey_amd import ops
     dev = _dev()
-    nimg, heads = 2, 3
     D = heads * 64
     pad = (ntok + 63) // 64 * 64
     qkv = torch.randn((3, nimg, heads, ntok, 64), generator=g(ntok)) * 1.5
