@@ -150,96 +150,120 @@ struct Stager {
 };
 
 // ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
-template <typename T, int WMF>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
-                                         int g) {
+// EPI / ACT / HAS_BIAS are compile-time inside the 32x unrolled store loop; epilogue() dispatches once per tile.
+template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
+                                              int g) {
+  using V4 = typename Lp<T>::V4;
   const int fr = lane & 15, fg = lane >> 4;
-  const float* bias = p.bias ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const int nb = n0 + wn * 64 + fg * 4;
+  f32x4 bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nb + ni * 16;
+    bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int mi = 0; mi < WMF; ++mi) {
     const int m = m0 + wm * (WMF * 16) + mi * 16 + fr;
     if (m >= p.M) continue;
     int img = 0, tok = 0;
-    if (p.epi == MK_EPI_QKV) {
+    if (EPI == MK_EPI_QKV) {
       img = m / p.ntok;
       tok = m - img * p.ntok;
-    } else if (p.epi == MK_EPI_PATCH) {
+    } else if (EPI == MK_EPI_PATCH) {
       img = m / p.npatch;
       tok = m - img * p.npatch;
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+      const int n = nb + ni * 16;
       if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
       f32x4 v = acc[mi][ni];
-      if (bias) {
-        const f32x4 b = *(const f32x4*)(bias + n);
-        v += b;
-      }
-      switch (p.epi) {
-        case MK_EPI_STORE: {
-          if (p.resid_lp) {
-            const typename Lp<T>::V4 r = *(const typename Lp<T>::V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g +
-                                                                  (long long)m * p.ldc + n);
+      if (HAS_BIAS) v += bv[ni];
+      if (EPI == MK_EPI_STORE) {
+        if (p.resid_lp) {
+          const V4 r = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-          }
-          if (p.act == MK_ACT_RELU) {
+          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+        if (ACT == MK_ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.act == MK_ACT_GELU) {
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ACT == MK_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          if (p.out_f32) {
-            *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = v;
-          } else {
-            typename Lp<T>::V4 o;
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.out_f32) {
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = v;
+        } else {
+          V4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
-            *(typename Lp<T>::V4*)((T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = o;
-          }
-        } break;
-        case MK_EPI_LS_RESIDUAL: {
-          float* x = p.out_f32 + (long long)m * p.ldc + n;
-          const f32x4 gm = *(const f32x4*)(p.gamma + n);
-          f32x4 r = *(const f32x4*)x;
-          r += gm * v;
-          *(f32x4*)x = r;
-        } break;
-        case MK_EPI_PATCH: {
-          const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
-          *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = v + pe;
-        } break;
-        case MK_EPI_QKV: {
-          const int D = p.heads * 64;
-          const int which = n / D;
-          const int rem = n - which * D;
-          const int head = rem >> 6, d = rem & 63;
-          const long long hb = (long long)img * p.heads + head;
-          if (which == 2) {
-            T* dst = (T*)p.vt + (hb * 64 + d) * p.ntok_pad + vperm(tok);
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          *(V4*)((T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = o;
+        }
+      } else if (EPI == MK_EPI_LS_RESIDUAL) {
+        float* x = p.out_f32 + (long long)m * p.ldc + n;
+        const f32x4 gm = *(const f32x4*)(p.gamma + n);
+        f32x4 r = *(const f32x4*)x;
+        r += gm * v;
+        *(f32x4*)x = r;
+      } else if (EPI == MK_EPI_PATCH) {
+        const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+        *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = v + pe;
+      } else {  // MK_EPI_QKV
+        const int D = p.heads * 64;
+        const int which = n / D;
+        const int rem = n - which * D;
+        const int head = rem >> 6, d = rem & 63;
+        const long long hb = (long long)img * p.heads + head;
+        if (which == 2) {
+          T* dst = (T*)p.vt + (hb * 64 + d) * p.ntok_pad + vperm(tok);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
-          } else {
-            if (which == 0) v *= p.qscale;
-            typename Lp<T>::V4 o;
+          for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
+        } else {
+          if (which == 0) v *= p.qscale;
+          V4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
-            T* base = (T*)(which == 0 ? p.q : p.k);
-            *(typename Lp<T>::V4*)(base + (hb * p.ntok_pad + tok) * 64 + d) = o;
-          }
-        } break;
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          T* base = (T*)(which == 0 ? p.q : p.k);
+          *(V4*)(base + (hb * p.ntok_pad + tok) * 64 + d) = o;
+        }
       }
     }
+  }
+}
+
+template <typename T, int WMF>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
+                                         int g) {
+  switch (p.epi) {   // wave-uniform, once per output tile
+    case MK_EPI_LS_RESIDUAL: epilogue_impl<T, WMF, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_QKV: epilogue_impl<T, WMF, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_PATCH: epilogue_impl<T, WMF, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    default:
+      if (!p.bias) {
+        if (p.act == MK_ACT_RELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, m0, n0, wm, wn, lane, g);
+        else epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, m0, n0, wm, wn, lane, g);
+      } else {
+        if (p.act == MK_ACT_RELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, m0, n0, wm, wn, lane, g);
+        else epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g);
+      }
   }
 }
 
 // WMF = 16-row M fragments per wave (4 -> 64 rows, 8 -> 128 rows); waves in an NWM x NWN grid, each wave 64 columns.
 //   <4,2,2>: 128x128 tile, 256 threads, 64 KiB LDS  (2 workgroups / CU)  -- small / skinny problems
 //   <8,2,4>: 256x256 tile, 512 threads, 128 KiB LDS (1 workgroup / CU)
-// Two LDS stages, the LDS-DMA of K tile kt+1 is issued before the MFMAs of tile kt, one barrier per K tile.
-template <typename T, int AMODE, int WMF, int NWM, int NWN>
+// Two LDS stages, the LDS-DMA of the next K tile is issued before the MFMAs of the current one, one barrier per K
+// tile.  PERSIST: the workgroup walks a sequence of output tiles and treats their K tiles as ONE stream -- the DMA of
+// the next tile's first K tile is issued before the last MFMAs of the current tile, and the epilogue's stores drain
+// under the next tile's main loop -- which removes the per-tile prologue bubble (no other workgroup shares the CU
+// to hide it when the tile needs 128 KiB of LDS).
+template <typename T, int AMODE, int WMF, int NWM, int NWN, bool PERSIST>
 __global__ __launch_bounds__(NWM* NWN * 64, (NWM * NWN) / 4) void gemm_kernel(GemmParams p) {
   using V8 = typename Lp<T>::V8;
   constexpr int NW = NWM * NWN, BM = NWM * WMF * 16, BN = NWN * 64;
@@ -253,47 +277,66 @@ __global__ __launch_bounds__(NWM* NWN * 64, (NWM * NWN) / 4) void gemm_kernel(Ge
   const int wm = wave / NWN, wn = wave % NWN;
   const int g = blockIdx.y;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  const int id = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+  const int ntiles = ntm * ntn;
+  const int nk = p.K / BK;
+  const int fr = lane & 15, fg = lane >> 4;
 
+  // tile sequence of this workgroup: ids blockIdx.x, +gridDim.x, ...; xcd_remap keeps the tiles that one XCD works on
+  // at any time adjacent (same A panel / neighbouring W panels in its L2)
+  int seq = blockIdx.x;
+  int id = xcd_remap(seq, ntiles);
+  int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
   Stager<T, AMODE, NW, AJ, WJ> st;
   st.init(p, g, m0, n0, wave, lane);
-
-  f32x4 acc[WMF][4];
-#pragma unroll
-  for (int i = 0; i < WMF; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
   st.issue(p, smem, smem + A_BYTES, 0);
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) st.issue(p, smem + ((kt + 1) & 1) * STAGE_BYTES, smem + ((kt + 1) & 1) * STAGE_BYTES + A_BYTES, kt + 1);
-    const char* sA = smem + (kt & 1) * STAGE_BYTES;
-    const char* sW = sA + A_BYTES;
+  int gi = 0;  // position in the K-tile stream (selects the LDS stage)
+  for (;;) {
+    f32x4 acc[WMF][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V8 wf[4], xf[WMF];
+    for (int i = 0; i < WMF; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rw = wn * 64 + i * 16 + fr;
-        wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cm0 = m0, cn0 = n0;
+    const int nseq = seq + gridDim.x;
+    const bool more = PERSIST && nseq < ntiles;
+    for (int kt = 0; kt < nk; ++kt, ++gi) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      char* nA = smem + ((gi + 1) & 1) * STAGE_BYTES;
+      if (kt + 1 < nk) {
+        st.issue(p, nA, nA + A_BYTES, kt + 1);
+      } else if (more) {  // first K tile of the next output tile
+        seq = nseq;
+        id = xcd_remap(seq, ntiles);
+        m0 = (id / ntn) * BM;
+        n0 = (id % ntn) * BN;
+        st.init(p, g, m0, n0, wave, lane);
+        st.issue(p, nA, nA + A_BYTES, 0);
       }
+      const char* sA = smem + (gi & 1) * STAGE_BYTES;
+      const char* sW = sA + A_BYTES;
 #pragma unroll
-      for (int i = 0; i < WMF; ++i) {
-        const int rx = wm * (WMF * 16) + i * 16 + fr;
-        xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+      for (int ks = 0; ks < 2; ++ks) {
+        V8 wf[4], xf[WMF];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rw = wn * 64 + i * 16 + fr;
+          wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+          const int rx = wm * (WMF * 16) + i * 16 + fr;
+          xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int mi = 0; mi < WMF; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
       }
-#pragma unroll
-      for (int mi = 0; mi < WMF; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
     }
+    epilogue<T, WMF>(p, acc, cm0, cn0, wm, wn, lane, g);
+    if (!more) break;
   }
-  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -302,18 +345,19 @@ __global__ __launch_bounds__(NWM* NWN * 64, (NWM * NWN) / 4) void gemm_kernel(Ge
 // barrier-delimited slot one wave-row executes its 32 MFMAs of a K tile from REGISTERS (its 12 fragments were
 // preloaded in the previous slot) while the other one issues LDS-DMA and reads its fragments, so each SIMD's matrix
 // pipe is fed by one wave while its partner does the memory work (s_setprio favours the MFMA wave).
-//   even slot 2kt  : wait(stage kt landed: counted vmcnt), barrier | row0: read frags(kt)        | row1: MFMA(kt-1) + DMA(kt+3)
-//   odd  slot 2kt+1: barrier                                       | row0: MFMA(kt) + DMA(kt+3)  | row1: read frags(kt)
-// Each wave issues its own 4 LDS-DMA pieces of a tile inside its MFMA slot (in the MFMA shadow), into the ring slot of
-// a tile whose last reader is at least one barrier behind; a DMA has >= 4 slots to land.  Barriers are bare
-// s_barrier: nothing ever drains the DMA queue to zero inside the loop.
+//   even slot 2kt  : wait(stage kt landed: counted vmcnt), barrier | row0: read frags(kt) + DMA a(kt+3) | row1: MFMA(kt-1) + DMA w(kt+2)
+//   odd  slot 2kt+1: barrier                                       | row0: MFMA(kt) + DMA w(kt+3)       | row1: read frags(kt) + DMA a(kt+3)
+// Each wave issues its own 4 LDS-DMA pieces of a tile (2 A pieces in its read slot, 2 W pieces in the following MFMA
+// slot) into the ring slot of a tile whose last reader is at least one barrier behind; a DMA has >= 4 slots to land.
+// Barriers are bare s_barrier: nothing ever drains the DMA queue to zero inside the loop.
 constexpr int PK = 32;          // K tile of the ping-pong kernel
 constexpr int PSTAGES = 4;
 
 // 64-byte LDS rows (4 chunks of 16 B): chunk' = chunk ^ ((-(row >> 2)) & 3) is conflict-free for ds_read_b128
 __device__ __forceinline__ int swz4(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
-template <typename T, int AMODE>
+// ABL: timing-ablation bits for tools/ (results are wrong when != 0): 1 = no LDS-DMA, 2 = no fragment reads, 4 = no barriers
+template <typename T, int AMODE, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   using V8 = typename Lp<T>::V8;
   constexpr int WMF = 8, NWN = 4, BM = 256, BN = 256;
@@ -360,9 +404,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   // one LDS-DMA instruction: piece q of K tile kt (q = 0,1: A pieces; 2,3: W pieces).  Every wave issues exactly
   // these 4 per K tile, in this order (the vmcnt arithmetic relies on it)
   auto issue_piece = [&](int kt, int q) {
+    if (ABL & 1) return;
     char* sA = smem + (kt % PSTAGES) * STAGE_BYTES;
     char* sW = sA + A_BYTES;
-    const int k0 = kt * PK;
+    const int k0 = (ABL & 8) ? 0 : kt * PK;   // ABL 8: always the same (cache-hot) source addresses
+    if (ABL & 16) {   // timing only: same instruction count, but each piece touches 8 full 128-B lines instead of 16 halves
+      const T* base = (q >= 2 ? wrow[q - 2] : A + aoff[q]) - (long long)(lane >> 2) * (q >= 2 ? p.ldw : p.lda);
+      glds16(base + (long long)(lane >> 3) * (q >= 2 ? p.ldw : p.lda) + ((lane >> 2) & 1) * 32 + k0,
+             (q >= 2 ? sW + (wave * 2 + (q - 2)) * 1024 : sA + (wave * 2 + q) * 1024));
+      return;
+    }
     if (q >= 2) {
       glds16(wrow[q - 2] + k0, sW + (wave * 2 + (q - 2)) * 1024);
     } else if (AMODE == A_DENSE) {
@@ -405,6 +456,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 
   const int fr = lane & 15, fg = lane >> 4;
   auto load_frags = [&](int kt) {
+    if ((ABL & 2) && kt > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wf[i]));
+#pragma unroll
+      for (int i = 0; i < WMF; ++i) asm volatile("" : "+v"(xf[i]));
+      return;
+    }
     const char* sA = smem + (kt % PSTAGES) * STAGE_BYTES;
     const char* sW = sA + A_BYTES;
 #pragma unroll
@@ -419,7 +477,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
   };
   const int nk = p.K / PK;
-  // 32 MFMAs from registers; the 4 LDS-DMA instructions of K tile `kt_dma` (if < nk) ride in the MFMA shadow
+  // 32 MFMAs from registers.  An LDS-DMA instruction stalls the issuing wave's MFMA stream for ~60-100 cycles
+  // (measured: all 4 pieces of a tile in this slot cost 19 %), so only pieces 2,3 (W) of tile `kt_dma` ride here;
+  // pieces 0,1 (A) are issued from the fragment-read slot, which has issue slack
   auto mfma_tile = [&](int kt_dma) {
     const bool dma = kt_dma < nk;
     __builtin_amdgcn_s_setprio(1);
@@ -427,62 +487,85 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     for (int mi = 0; mi < WMF; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
-      if ((mi & 1) && dma) issue_piece(kt_dma, mi >> 1);
+      if (dma && mi == 2) issue_piece(kt_dma, 2);
+      if (dma && mi == 5) issue_piece(kt_dma, 3);
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+  auto read_slot = [&](int kt) {   // fragment reads of tile kt + the first half of the DMA of tile kt+3
+    load_frags(kt);
+    if (kt + 3 < nk) {
+      issue_piece(kt + 3, 0);
+      issue_piece(kt + 3, 1);
+    }
   };
 
   issue(0);
   if (nk > 1) issue(1);
   if (nk > 2) issue(2);
-  if (wm == 1 && nk > 3) issue(3);   // wave-row 1 idles in slot 0: it pre-issues its share of tile 3
-  // even-slot entry: this wave's LDS-DMA of tile kt has landed once at most the 4 * (tiles issued after kt) newest
-  // DMAs are outstanding (both wave-rows have issued up to tile kt+2 at that point); the barrier then makes every
-  // wave's share of tile kt visible
-  auto even_entry = [&](int kt) {
+  // even-slot entry: wait until this wave's LDS-DMA of tile kt has landed = at most `allow` newer DMA instructions
+  // outstanding, then the barrier makes every wave's share of tile kt visible.  Wave-row 0 has issued tiles <= kt+2
+  // completely at that point; wave-row 1 has issued tile kt+1 completely and pieces 0,1 of tile kt+2.
+  auto even_entry = [&](int kt, int half_issued) {
     const int newer = nk - 1 - kt;
-    if (newer >= 2)
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (newer == 1)
+    if (newer >= 2) {
+      if (half_issued)
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    } else if (newer == 1) {
       asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else
+    } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    }
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
   };
   auto odd_entry = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
   };
   // the two wave-rows run separate straight-line loops (same number of barriers per K tile), so the accumulators
   // never flow through a conditional merge
   if (wm == 0) {
     for (int kt = 0; kt < nk; ++kt) {
-      even_entry(kt);
-      load_frags(kt);
+      even_entry(kt, 0);
+      read_slot(kt);       // slot 2kt  : ring slot (kt+3)%4 was last read in slot 2kt-1
       odd_entry();
-      mfma_tile(kt + 3);   // slot 2kt+1: ring slot (kt+3)%4 was last read in slot 2kt-1
+      mfma_tile(kt + 3);   // slot 2kt+1
     }
   } else {
     // same barrier sequence, loop boundary shifted by one slot so that fragments are loaded and consumed inside
     // one iteration (no loop-carried fragment registers)
-    even_entry(0);
+    even_entry(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       odd_entry();
-      load_frags(kt);
-      if (kt + 1 < nk) even_entry(kt + 1);
-      mfma_tile(kt + 4);   // slot 2kt+2: ring slot kt%4 was last read in slot 2kt+1 (by this wave-row)
+      read_slot(kt);                          // slot 2kt+1
+      if (kt + 1 < nk) even_entry(kt + 1, 1);
+      mfma_tile(kt + 3);                      // slot 2kt+2
     }
   }
   epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+}
+
+int g_num_cus = 0;
+int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cus = n;
+  }
+  return g_num_cus;
 }
 
 template <typename T, int AMODE, int WMF, int NWM, int NWN>
 int launch_cfg(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = NWM * WMF * 16, BN = NWN * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr bool PERSIST = WMF == 8;   // the 128-KiB-LDS tile owns its CU: walk the tiles persistently
   static bool attr_done = false;  // benign race: the attribute call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, NWM, NWN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, NWM, NWN, PERSIST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
@@ -491,17 +574,22 @@ int launch_cfg(const GemmParams& p, int groups, hipStream_t st) {
     attr_done = true;
   }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, NWM, NWN>), dim3(ntm * ntn, groups, 1), dim3(NWM * NWN * 64), LDS, st, p);
+  int gx = ntm * ntn;
+  if (PERSIST) {
+    const int cap = (num_cus() + groups - 1) / groups;   // one resident workgroup per CU in total
+    if (gx > cap) gx = cap;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, NWM, NWN, PERSIST>), dim3(gx, groups, 1), dim3(NWM * NWN * 64), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
 
-template <typename T, int AMODE>
+template <typename T, int AMODE, int ABL = 0>
 int launch_pp(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int LDS = PSTAGES * 512 * 64;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<T, AMODE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -509,7 +597,7 @@ int launch_pp(const GemmParams& p, int groups, hipStream_t st) {
     attr_done = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  hipLaunchKernelGGL((gemm_pp_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL((gemm_pp_kernel<T, AMODE, ABL>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -525,6 +613,21 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   if (g_force_tile == 2) big = true;
   if (g_force_tile == 3)
     return dtype == MK_BF16 ? launch_pp<__bf16, AMODE>(p, groups, st) : launch_pp<_Float16, AMODE>(p, groups, st);
+  if (g_force_tile >= 10 && g_force_tile < 21 && AMODE == A_DENSE && dtype == MK_BF16) {  // timing ablations (wrong results)
+    switch (g_force_tile - 10) {
+      case 1: return launch_pp<__bf16, A_DENSE, 1>(p, groups, st);
+      case 2: return launch_pp<__bf16, A_DENSE, 2>(p, groups, st);
+      case 3: return launch_pp<__bf16, A_DENSE, 3>(p, groups, st);
+      case 4: return launch_pp<__bf16, A_DENSE, 4>(p, groups, st);
+      case 5: return launch_pp<__bf16, A_DENSE, 5>(p, groups, st);
+      case 6: return launch_pp<__bf16, A_DENSE, 6>(p, groups, st);
+      case 7: return launch_pp<__bf16, A_DENSE, 7>(p, groups, st);
+      case 8: return launch_pp<__bf16, A_DENSE, 8>(p, groups, st);
+      case 9: return launch_pp<__bf16, A_DENSE, 16>(p, groups, st);
+      case 10: return launch_pp<__bf16, A_DENSE, 24>(p, groups, st);
+      default: break;
+    }
+  }
   if (dtype == MK_BF16)
     return big ? launch_cfg<__bf16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<__bf16, AMODE, 4, 2, 2>(p, groups, st);
   return big ? launch_cfg<_Float16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<_Float16, AMODE, 4, 2, 2>(p, groups, st);
@@ -545,7 +648,7 @@ int check_common(const GemmParams& p, int dtype) {
 extern "C" {
 
 int mk_gemm_set_tile(int mode) {
-  MK_CHECK_ARG(mode >= 0 && mode <= 3, "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
+  MK_CHECK_ARG((mode >= 0 && mode <= 3) || (mode >= 10 && mode < 21), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
   g_force_tile = mode;
   return MK_OK;
 }
@@ -580,7 +683,7 @@ int mk_gemm_ls_residual(const void* A, int lda, const void* W, int ldw, const fl
   p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
   p.epi = MK_EPI_LS_RESIDUAL; p.bias = bias; p.gamma = gamma; p.out_f32 = x; p.ldc = ldx;
   if (int e = check_common(p, dtype)) return e;
-  MK_CHECK_ARG(gamma && x && lda % 8 == 0 && lda >= K && ldx % 4 == 0 && ldx >= N, "mk_gemm_ls_residual: bad args");
+  MK_CHECK_ARG(bias && gamma && x && lda % 8 == 0 && lda >= K && ldx % 4 == 0 && ldx >= N, "mk_gemm_ls_residual: bad args");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
@@ -592,7 +695,7 @@ int mk_gemm_qkv(const void* A, int lda, const void* W, int ldw, const float* bia
   p.epi = MK_EPI_QKV; p.bias = bias; p.q = q; p.k = k; p.vt = vt;
   p.ntok = ntok; p.ntok_pad = ntok_pad; p.heads = heads; p.qscale = qscale;
   if (int e = check_common(p, dtype)) return e;
-  MK_CHECK_ARG(q && k && vt && ntok_pad % 64 == 0 && ntok_pad >= ntok && lda % 8 == 0 && lda >= D, "mk_gemm_qkv: bad args");
+  MK_CHECK_ARG(bias && q && k && vt && ntok_pad % 64 == 0 && ntok_pad >= ntok && lda % 8 == 0 && lda >= D, "mk_gemm_qkv: bad args");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
@@ -602,7 +705,7 @@ int mk_gemm_patch_embed(const void* A, int lda, const void* W, int ldw, const fl
   p.A = A; p.W = W; p.M = nimg * npatch; p.N = D; p.K = K; p.lda = lda; p.ldw = ldw;
   p.epi = MK_EPI_PATCH; p.bias = bias; p.pos = pos; p.npatch = npatch; p.out_f32 = x; p.ldc = D;
   if (int e = check_common(p, dtype)) return e;
-  MK_CHECK_ARG(pos && x && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed: bad args");
+  MK_CHECK_ARG(bias && pos && x && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed: bad args");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 

@@ -35,7 +35,7 @@ def _auto_tile():
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])
 def test_gemm_bias_act(dtype, M, N, K, tile):
     from mickey_amd import ops
     dev = _dev()
