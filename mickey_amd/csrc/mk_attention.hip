@@ -107,23 +107,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             if (key >= ntok) s[qb][kb][r] = -1e30f;
           }
       }
-      float mx = s[qb][0][0];
+      // max over the lane's 32 scores as a shallow tree of 3-input maxima (v_max3_f32), not a 31-deep chain
+      float t8[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[qb][0][r], s[qb][1][r]));
+      for (int r = 0; r < 8; ++r)
+        t8[r] = fmaxf(fmaxf(s[qb][0][r], s[qb][0][r + 8]), fmaxf(s[qb][1][r], s[qb][1][r + 8]));
+      float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+      mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // raw v_exp_f32 (exp2f() would add ~5 range-fixup instructions per element; arguments here are <= 0 and
       // results below the normal range may flush to zero, which is what a softmax tail wants anyway)
       const float m_new = fmaxf(m_run[qb], mx);
       const bool grew = m_new > m_run[qb];
-      float rs = 0.f;
+      float rs4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 32-deep dependent add chain
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
           s[qb][kb][r] = pv;
-          rs += pv;
+          rs4[r & 3] += pv;
         }
+      const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
       if (__any(grew)) {   // wave-uniform: after the first tiles the running max rarely moves -> no O rescale
         const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
         l_run[qb] *= alpha;
