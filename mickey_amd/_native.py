@@ -29,6 +29,7 @@ SIGNATURES = {
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
     "mk_layernorm": ("i", "pippfpiipiiiiiiip"),
+    "mk_attn_set_mode": ("i", "i"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_conv3x3": ("i", "pliplipilplppiliiiiiipip"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),

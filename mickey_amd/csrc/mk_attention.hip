@@ -4,6 +4,8 @@
 //
 // Design (wave64, v_mfma_f32_32x32x16):
 //  * workgroup = 4 waves of one (image, head); each wave owns 32 or 64 queries (QB sub-blocks of 32).
+//  * four variants share this design (mk_attn_set_mode): the default is attn_fwd_lean_kernel, which strips the softmax
+//    to ~70 VALU instructions per tile (max folded into the accumulator init, row sums on the matrix pipe).
 //  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
 //    (lane-linear image; XOR swizzle on the source address + on the ds_read_b128), double-buffered.
 //  * S^T = K.Q^T ("swapped" product): after the MFMA a lane holds 32 scores of ONE query, so the
@@ -177,12 +179,334 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// Software-pipelined variant (32 queries per wave): the QK^T MFMAs of KV tile t+1 are issued BEFORE the softmax VALU
+// work of tile t (S is double-buffered in registers), so within one wave the matrix pipe computes S(t+1) while the
+// VALU exponentiates S(t); then P(t).V(t).  K therefore runs one tile ahead of V in the LDS double buffers.
+template <typename T>
+__global__ __launch_bounds__(256, 3) void attn_fwd_pipe_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ vt, T* __restrict__ out, int ldo,
+                                                               int heads, int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2] | Vt[2]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int head = blockIdx.y, img = blockIdx.z;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int j = lane & 31, hi = lane >> 5;
+
+  V8 qf[4];
+  {
+    int qrow = q0 + j;
+    qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  }
+  const int srow = lane >> 3, sp = lane & 7;
+  auto stage_k = [&](int kt) {
+    char* sK = smem + (kt & 1) * KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ii = wave * 2 + t, r = ii * 8 + srow;
+      glds16(Kh + (long long)(kt * 64 + r) * 64 + swz8(r, sp) * 8, sK + ii * 1024);
+    }
+  };
+  auto stage_v = [&](int kt) {
+    char* sV = smem + (2 + (kt & 1)) * KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ii = wave * 2 + t, r = ii * 8 + srow;
+      glds16(Vh + (long long)r * ntok_pad + kt * 64 + swz8(r, sp) * 8, sV + ii * 1024);
+    }
+  };
+  auto qk = [&](int kt, f32x16 (&s)[2]) {   // S^T(kt) = K(kt) . Q^T
+    const char* sK = smem + (kt & 1) * KV_TILE_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      const int row = kb * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 2 + hi) * 16);
+        s[kb] = Lp<T>::mma32(kf, qf[ks], s[kb]);
+      }
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int nkt = (ntok + 63) >> 6;
+
+  // one pipeline step: s_cur = S(t) (already computed), s_nxt receives S(t+1)
+  auto step = [&](int t, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V(t) and K(t+1) (issued one step ago) have landed
+    __syncthreads();
+    if (t + 1 < nkt) stage_v(t + 1);   // buffer of V(t-1): its readers are behind the barrier
+    if (t + 2 < nkt) stage_k(t + 2);   // buffer of K(t): read one step ago
+    if (t + 1 < nkt) qk(t + 1, s_nxt); // matrix pipe works on S(t+1) ...
+    __builtin_amdgcn_sched_barrier(0);
+    // ... while the VALU does the softmax of S(t)
+    if (t == nkt - 1 && (ntok & 63)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= ntok) s_cur[kb][r] = -1e30f;
+        }
+    }
+    float t8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s_cur[0][r], s_cur[0][r + 8]), fmaxf(s_cur[1][r], s_cur[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+    mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const bool grew = m_new > m_run;
+    float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s_cur[kb][r] - m_new);
+        s_cur[kb][r] = pv;
+        rs4[r & 3] += pv;
+      }
+    if (__any(grew)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+    }
+    m_run = m_new;
+    l_run += (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+    V8 pf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)s_cur[s4 >> 1][(s4 & 1) * 8 + e];
+    const char* sV = smem + (2 + (t & 1)) * KV_TILE_BYTES;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int row = dt * 32 + j;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
+        o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
+      }
+    }
+  };
+
+  f32x16 sa[2], sb[2];
+  stage_k(0);
+  stage_v(0);
+  if (nkt > 1) stage_k(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  qk(0, sa);
+  for (int t = 0; t < nkt; t += 2) {
+    step(t, sa, sb);
+    if (t + 1 < nkt) step(t + 1, sb, sa);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + j;
+  if (qi < ntok) {
+    T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        V4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][r4 * 4 + e] * inv);
+        *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
+// VALU-lean variant (32 queries per wave).  A wave64 VALU instruction costs ~4 issue cycles and a 32-cycle MFMA hides
+// only a handful of them, so the softmax (~170 VALU instructions per 16 MFMAs) bounds the kernels above.  Here:
+//  * the running maximum is folded into the QK^T accumulator init: S' = K.Q^T + (-m) comes out of the MFMA already
+//    shifted (a persistent 16-register vector holds -m; no per-element subtraction);
+//  * m is only re-based when a tile's maximum exceeds it by more than 2^8 (then O and the row sums are rescaled);
+//    otherwise P = exp2(S') <= 256 is used as is -- the common case after the first tile;
+//  * the row sums are computed on the matrix pipe (ones . P^T, 4 extra MFMAs per tile) instead of 32 VALU adds; they
+//    sum the same 16-bit P that multiplies V, and need no cross-lane exchange.
+// Per tile and wave: 20 MFMAs and ~70 VALU instructions (16 max3, 32 exp, 16 cvt).
+constexpr float ATT_REBASE_THR = 8.0f;
+
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 3 : 2) void attn_fwd_lean_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ vt, T* __restrict__ out, int ldo,
+                                                               int heads, int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int head = blockIdx.y, img = blockIdx.z;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = blockIdx.x * (NWAVES * 32) + wave * 32;
+  const int j = lane & 31, hi = lane >> 5;
+
+  V8 qf[4];
+  {
+    int qrow = q0 + j;
+    qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  }
+  V8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+
+  const int srow = lane >> 3, sp = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * KV_TILE_BYTES;
+    char* sV = sK + KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 8 / NWAVES; ++t) {   // 8 one-KiB pieces per operand tile, spread over the waves
+      const int ii = wave * (8 / NWAVES) + t;
+      const int r = ii * 8 + srow;
+      glds16(Kh + (long long)(kt * 64 + r) * 64 + swz8(r, sp) * 8, sK + ii * 1024);
+      glds16(Vh + (long long)r * ntok_pad + kt * 64 + swz8(r, sp) * 8, sV + ii * 1024);
+    }
+  };
+
+  f32x16 o[2], lsum, negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    o[0][i] = o[1][i] = 0.f;
+    lsum[i] = 0.f;
+    negm[i] = 0.f;          // m_run = 0 to start with; the first tile re-bases (scores are bounded by |q||k|)
+  }
+  float m_run = 0.f;
+  bool first = true;
+
+  const int nkt = (ntok + 63) >> 6;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+    const char* sV = sK + KV_TILE_BYTES;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = kb * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 2 + hi) * 16);
+        s[kb] = Lp<T>::mma32(kf, qf[ks], ks == 0 ? negm : s[kb]);   // S' = K.Q^T - m
+      }
+    }
+    if (kt == nkt - 1 && (ntok & 63)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= ntok) s[kb][r] = -1e30f;
+        }
+    }
+    float t8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+    mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
+    if (__any(mx > ATT_REBASE_THR) || first) {   // wave-uniform, rare after the first tile: re-base m to this tile's maximum
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile
+      const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+        lsum[i] *= alpha;
+        s[0][i] -= shift;
+        s[1][i] -= shift;
+      }
+      m_run += shift;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -m_run;
+      first = false;
+    }
+    V8 pf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)__builtin_amdgcn_exp2f(s[s4 >> 1][(s4 & 1) * 8 + e]);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) lsum = Lp<T>::mma32(ones, pf[s4], lsum);   // row sums on the matrix pipe
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int row = dt * 32 + j;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
+        o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
+      }
+    }
+  }
+
+  const float inv = 1.0f / lsum[0];   // every accumulator row of ones.P^T holds the full row sum of this lane's query
+  const int qi = q0 + j;
+  if (qi < ntok) {
+    T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        V4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][r4 * 4 + e] * inv);
+        *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
+int g_attn_mode = 0;   // 0 auto, 1: 32 q/wave, 2: 64 q/wave, 3: software-pipelined (mk_attn_set_mode)
+
 template <typename T>
 void launch_attn(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads, int ntok, int ntok_pad,
                  hipStream_t st) {
   // 64 queries per wave once that still leaves >= 2 workgroups per CU; 32 queries per wave for small batches
   const long long blocks2 = (long long)((ntok + 255) / 256) * heads * nimg;
-  if (blocks2 >= 512)
+  if (g_attn_mode == 4 || g_attn_mode == 0) {   // default: measured fastest at every batch size (tools/bench_kernels.py)
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<T, 4>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+    return;
+  }
+  if (g_attn_mode == 5) {
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<T, 8>), dim3((ntok + 255) / 256, heads, nimg), dim3(512), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+    return;
+  }
+  if (g_attn_mode == 3) {
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<T>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+    return;
+  }
+  if (g_attn_mode == 2 || (g_attn_mode == 0 && blocks2 >= 512))
     hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   else
@@ -191,6 +515,12 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }
 
 }  // namespace
+
+extern "C" int mk_attn_set_mode(int mode) {
+  MK_CHECK_ARG(mode >= 0 && mode <= 5, "mk_attn_set_mode: 0 auto, 1 = 32 q/wave, 2 = 64 q/wave, 3 = pipelined, 4 = VALU-lean, 5 = VALU-lean 8 waves");
+  g_attn_mode = mode;
+  return MK_OK;
+}
 
 extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads,
                                  int ntok, int ntok_pad, int dtype, mk_stream_t stream) {

@@ -97,6 +97,11 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
     return out
 
 
+def attn_set_mode(mode):
+    """0 auto, 1 = 32 queries/wave, 2 = 64 queries/wave, 3 = software-pipelined (tests / benchmarks)."""
+    call("mk_attn_set_mode", int(mode))
+
+
 def flash_attn(q, k, vt, out, nimg, heads, ntok, ntok_pad):
     call("mk_flash_attn_fwd", ptr(q), ptr(k), ptr(vt), ptr(out), out.stride(0), nimg, heads, ntok, ntok_pad,
          dtype_code(q.dtype), stream())

@@ -31,6 +31,7 @@ def _auto_tile():
     if torch.cuda.is_available():
         from mickey_amd import ops
         ops.gemm_set_tile(0)
+        ops.attn_set_mode(0)
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
@@ -142,11 +143,14 @@ def test_layernorm(D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode", [0, 3, 4, 5])
 @pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])
-def test_flash_attention(dtype, ntok, nimg, heads):
-    """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the 64-queries-per-wave instantiation."""
+def test_flash_attention(dtype, ntok, nimg, heads, mode):
+    """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the 64-queries-per-wave instantiation in auto
+    mode; mode 3 is the software-pipelined kernel."""
     from mickey_amd import ops
     dev = _dev()
+    ops.attn_set_mode(mode)
     D = heads * 64
     pad = (ntok + 63) // 64 * 64
     qkv = torch.randn((3, nimg, heads, ntok, 64), generator=g(ntok)) * 1.5

@@ -44,16 +44,19 @@ def main():
                 res.append({"kernel": "gemm_" + name, "tile": tile, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf})
                 print(res[-1], flush=True)
             ops.gemm_set_tile(0)
-    for nimg in (2, 16):
+    for nimg in (2, 16, 64):
         heads, ntok, pad = 16, 1939, 1984
         q = (torch.randn((nimg, heads, pad, 64), device=dev) * 0.2).bfloat16()
         k = torch.randn((nimg, heads, pad, 64), device=dev).bfloat16()
         vt = torch.randn((nimg, heads, 64, pad), device=dev).bfloat16()
         out = torch.empty((nimg * ntok, heads * 64), device=dev, dtype=torch.bfloat16)
-        t = timeit(lambda: ops.flash_attn(q, k, vt, out, nimg, heads, ntok, pad))
-        tf = 4.0 * nimg * heads * ntok * ntok * 64 / t / 1e12
-        res.append({"kernel": "flash_attn", "nimg": nimg, "ms": t * 1e3, "TFLOPs": tf})
-        print(res[-1], flush=True)
+        for mode in (2, 4, 5):
+            ops.attn_set_mode(mode)
+            t = timeit(lambda: ops.flash_attn(q, k, vt, out, nimg, heads, ntok, pad))
+            tf = 4.0 * nimg * heads * ntok * ntok * 64 / t / 1e12
+            res.append({"kernel": "flash_attn", "mode": mode, "nimg": nimg, "ms": t * 1e3, "TFLOPs": tf})
+            print(res[-1], flush=True)
+        ops.attn_set_mode(0)
     for M in (3878, 3878 * 8):
         x = torch.randn((M, 1024), device=dev)
         w = torch.ones(1024, device=dev)

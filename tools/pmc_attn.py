@@ -7,6 +7,7 @@ q = (torch.randn((nimg, heads, pad, 64), device=dev) * 0.2).bfloat16()
 k = torch.randn((nimg, heads, pad, 64), device=dev).bfloat16()
 vt = torch.randn((nimg, heads, 64, pad), device=dev).bfloat16()
 out = torch.empty((nimg * ntok, heads * 64), device=dev, dtype=torch.bfloat16)
+ops.attn_set_mode(int(os.environ.get("ATTN_MODE", "0")))
 for _ in range(3):
     ops.flash_attn(q, k, vt, out, nimg, heads, ntok, pad)
 torch.cuda.synchronize()
