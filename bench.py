@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="mk_gemm_set_tile mode (0 = automatic)")
+    ap.add_argument("--attn-mode", type=int, default=0, help="mk_attn_set_mode mode (0 = default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +119,8 @@ def main():
     from mickey_amd.config import default_cfg
     from mickey_amd.model import MickeyRelativePose
 
+    ops.gemm_set_tile(args.gemm_tile)
+    ops.attn_set_mode(args.attn_mode)
     cfg = default_cfg()
     cfg["AMD"]["ENCODER_DTYPE"] = args.dtype
     cfg["AMD"]["SEED"] = rank

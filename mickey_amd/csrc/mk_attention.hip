@@ -4,8 +4,8 @@
 //
 // Design (wave64, v_mfma_f32_32x32x16):
 //  * workgroup = 4 waves of one (image, head); each wave owns 32 or 64 queries (QB sub-blocks of 32).
-//  * four variants share this design (mk_attn_set_mode): the default is attn_fwd_lean_kernel, which strips the softmax
-//    to ~70 VALU instructions per tile (max folded into the accumulator init, row sums on the matrix pipe).
+//  * four variants share this design (mk_attn_set_mode); attn_fwd_lean_kernel strips the softmax to ~70 VALU
+//    instructions per tile (max folded into the accumulator init, row sums on the matrix pipe).
 //  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
 //    (lane-linear image; XOR swizzle on the source address + on the ds_read_b128), double-buffered.
 //  * S^T = K.Q^T ("swapped" product): after the MFMA a lane holds 32 scores of ONE query, so the
@@ -491,7 +491,9 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
                  hipStream_t st) {
   // 64 queries per wave once that still leaves >= 2 workgroups per CU; 32 queries per wave for small batches
   const long long blocks2 = (long long)((ntok + 255) / 256) * heads * nimg;
-  if (g_attn_mode == 4 || g_attn_mode == 0) {   // default: measured fastest at every batch size (tools/bench_kernels.py)
+  // default: 64-query waves for large grids (fastest inside the full forward, bench.py --attn-mode A/B), the VALU-lean
+  // kernel for small ones (fastest at B = 1)
+  if (g_attn_mode == 4 || (g_attn_mode == 0 && blocks2 < 512)) {
     hipLaunchKernelGGL((attn_fwd_lean_kernel<T, 4>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
     return;

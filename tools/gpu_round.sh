@@ -1,10 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/pytest_gpu.log
-tail -4 gpurun_out/pytest_gpu.log | cut -c1-300
-timeout 1200 python bench.py > gpurun_out/bench.log 2>&1
-tail -1 gpurun_out/bench.log | cut -c1-1700
-timeout 600 python bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_b1.log 2>&1
-tail -1 gpurun_out/bench_b1.log | cut -c1-200
+for i in 1 2; do
+for t in 0 4; do
+  echo "gemm-tile $t:" $(python bench.py --steps 4 --warmup 2 --no-cpu-baseline --gemm-tile $t 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'])")
+done
+done
+for a in 2 4; do
+  echo "attn-mode $a:" $(python bench.py --steps 4 --warmup 2 --no-cpu-baseline --attn-mode $a 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'])")
+done
