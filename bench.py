@@ -110,9 +110,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run (any world size)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from mickey_amd import distributed as D
     from mickey_amd import ops, synthetic as syn
@@ -138,14 +139,14 @@ def main():
     def step():
         data = dict(data0)
         R, t = model(data)
-        if world > 1:
-            D.gather_poses(R, t, data["inliers"])
+        if use_dist:
+            data["poses_all"] = D.gather_poses(R, t, data["inliers"])   # the one collective: [B_local,13] -> [world*B_local,13]
         return data
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     prof.on = True
@@ -153,12 +154,13 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof.on = False
-    if world > 1:
+    if use_dist:
+        assert last["poses_all"][0].shape[0] == world * B
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -189,7 +191,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

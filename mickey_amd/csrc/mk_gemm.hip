@@ -555,6 +555,201 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong with FULL-LINE LDS-DMA pieces: 256x256 tile, 8 waves (wave-row g = wave>>2), LDS stages of K = 64
+// (128-byte rows, the swz8 swizzle of the plain kernel), computed in two K = 32 sub-steps h.  A piece is 8 rows x
+// 128 B (8 full cache lines; the K = 32 ring above moves 16 half lines per piece, measured 12 % slower).  Only two
+// 64-KiB stages fit, which is deep enough because the operand halves are released at different times:
+//   * wave-row g loads AND reads only its own A half (rows 128g..128g+127); W is loaded and read by everyone;
+//   * slots (barrier at every boundary):  row g does  L(kt,h) [12 fragment reads] in slot 4kt+2h+g  and
+//     C(kt,h) [32 MFMAs from registers] in slot 4kt+2h+g+1;
+//   * A_g(kt+2) is issued in row g's C(kt,1) slot (its last reader, L(kt,1) of the same row, is one barrier behind);
+//     W(kt+1) is issued in row g's L(kt,0) slot (the last reader of W(kt-1), row 1 in slot 4kt-1, is behind);
+//   * every DMA has 3-5 slots to land; once per stage a counted vmcnt at the end of slot 4kt+3 (row 0: 4 newer DMAs
+//     may stay in flight; row 1: 0) precedes the barrier that opens stage kt+1.
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
+  using V8 = typename Lp<T>::V8;
+  constexpr int WMF = 8, BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;   // 64 KiB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = blockIdx.y;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int id = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  const T* A = (const T*)p.A + (long long)g * p.strideA_g;
+  const T* A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+  const T* W = (const T*)p.W + (long long)g * p.strideW_g;
+  const int srow = lane >> 3, sp = lane & 7;
+  // this wave's 4 A pieces (own half) and 4 W pieces; piece = 8 rows
+  const T* wrow[4];
+  long long aoff[4];
+  int ay[4], ax[4];
+  bool avalid[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rw = (wave * 4 + j) * 8 + srow;
+    int n = n0 + rw;
+    n = n < p.N ? n : p.N - 1;
+    wrow[j] = W + (long long)n * p.ldw + swz8(rw, sp) * 8;
+    const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
+    int m = m0 + ra;
+    avalid[j] = m < p.M;
+    m = avalid[j] ? m : p.M - 1;
+    if (AMODE == A_DENSE) {
+      aoff[j] = (long long)m * p.lda + swz8(ra, sp) * 8;
+      ay[j] = ax[j] = 0;
+    } else {
+      const int pix = m % (p.H * p.Wd);
+      ay[j] = pix / p.Wd;
+      ax[j] = pix % p.Wd;
+      aoff[j] = m;
+    }
+  }
+  const int nk = p.K / BK;
+  auto dma_w = [&](int kt) {   // 4 instructions
+    if (kt >= nk) return;
+    char* sW = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(wrow[j] + kt * BK, sW + (wave * 4 + j) * 1024);
+  };
+  auto dma_a = [&](int kt) {   // 4 instructions
+    if (kt >= nk) return;
+    char* sA = smem + (kt & 1) * STAGE_BYTES;
+    const int k0 = kt * BK;
+    if (AMODE == A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) glds16(A + aoff[j] + k0, sA + (wm * 16 + wn * 4 + j) * 1024);
+    } else {
+      const int kc = 9 * p.C1;
+      const T* src;
+      int cs, c0, dy, dx;
+      if (k0 < kc) {
+        const int tap = k0 / p.C1;
+        c0 = k0 - tap * p.C1;
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+        src = A;
+        cs = p.C1;
+      } else {
+        c0 = k0 - kc;
+        dy = dx = 0;
+        src = A2;
+        cs = p.C2;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
+        const int yy = ay[j] + dy, xx = ax[j] + dx;
+        const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+        const T* sp_ = ok ? src + (aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
+        glds16(sp_, sA + (wm * 16 + wn * 4 + j) * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[WMF][4];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V8 wf[4], xf[WMF];
+  const int fr = lane & 15, fg = lane >> 4;
+  auto load_frags = [&](int kt, int h) {
+    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rw = wn * 64 + i * 16 + fr;
+      wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, h * 4 + fg) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WMF; ++i) {
+      const int rx = wm * 128 + i * 16 + fr;
+      xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, h * 4 + fg) * 16);
+    }
+  };
+  auto mfma32 = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < WMF; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // prologue: stage 0 (own A half + W share) and the own A half of stage 1
+  dma_a(0);
+  dma_w(0);
+  dma_a(1);
+  if (nk > 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      bar();                      // slot 4kt
+      load_frags(kt, 0);
+      dma_w(kt + 1);
+      bar();                      // slot 4kt+1
+      mfma32();
+      bar();                      // slot 4kt+2
+      load_frags(kt, 1);
+      bar();                      // slot 4kt+3
+      mfma32();
+      dma_a(kt + 2);
+      if (kt + 2 < nk)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    bar();                        // slot 0: this wave-row idles
+    for (int kt = 0; kt < nk; ++kt) {
+      bar();                      // slot 4kt+1
+      load_frags(kt, 0);
+      dma_w(kt + 1);
+      bar();                      // slot 4kt+2
+      mfma32();
+      bar();                      // slot 4kt+3
+      load_frags(kt, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
+      if (kt + 1 < nk) bar();     // slot 4kt+4
+      mfma32();
+      dma_a(kt + 2);
+    }
+  }
+  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+}
+
+template <typename T, int AMODE>
+int launch_pp64(const GemmParams& p, int groups, hipStream_t st) {
+  constexpr int LDS = 2 * 512 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MK_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
 int g_num_cus = 0;
 int num_cus() {
   if (g_num_cus == 0) {
@@ -619,6 +814,8 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
   if (g_force_tile == 1) big = false;
   if (g_force_tile == 2) big = true;
+  if (g_force_tile == 5 || (g_force_tile == 6 && big))
+    return dtype == MK_BF16 ? launch_pp64<__bf16, AMODE>(p, groups, st) : launch_pp64<_Float16, AMODE>(p, groups, st);
   if (g_force_tile == 3 || (g_force_tile == 4 && big))
     return dtype == MK_BF16 ? launch_pp<__bf16, AMODE>(p, groups, st) : launch_pp<_Float16, AMODE>(p, groups, st);
   if (g_force_tile >= 10 && g_force_tile < 22 && AMODE == A_DENSE && dtype == MK_BF16) {  // timing ablations (wrong results)
@@ -657,7 +854,7 @@ int check_common(const GemmParams& p, int dtype) {
 extern "C" {
 
 int mk_gemm_set_tile(int mode) {
-  MK_CHECK_ARG((mode >= 0 && mode <= 4) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
+  MK_CHECK_ARG((mode >= 0 && mode <= 6) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
   g_force_tile = mode;
   return MK_OK;
 }

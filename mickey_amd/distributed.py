@@ -43,7 +43,7 @@ def gather_poses(R, t, conf, sizes=None):
     """All ranks receive the poses of the whole global batch, in global pair order.  `sizes` = per-rank
     shard sizes when they differ (ragged last batch); equal shards take the single-collective path."""
     packed = pack_poses(R, t, conf)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return unpack_poses(packed)
     world = dist.get_world_size()
     if sizes is None or len(set(sizes)) == 1:

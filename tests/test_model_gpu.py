@@ -165,3 +165,26 @@ def test_cpu_module_raises(cfg):
     m.load_state_dict(syn.mickey_state_dict(cfg, arch="vit_tiny_test"))
     with pytest.raises(_native.MickeyHipError):
         m(syn.synthetic_batch(B=1, H=56, W=56))
+
+
+def test_config5_720p_sinkhorn_fp16(cfg):
+    """BASELINE.json config #5: 1280x720 input (51x91 grid, n = 4641), Sinkhorn matcher, fp16 MFMA operands.
+    (The reference's Sinkhorn branch is unreachable through its own forward; the maths is checked
+    against the oracle's restatement of feature_matcher.py:93-137 on the descriptors the HIP path produced.)"""
+    import copy
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    from oracle import mickey_oracle as O
+    c = copy.deepcopy(cfg)
+    c["FEATURE_MATCHER"]["TYPE"] = "Sinkhorn"
+    model, sd = _model(c, "fp16")
+    batch = syn.synthetic_batch(B=1, H=720, W=1280, seed=7)
+    data = {k: v.to(dev) for k, v in batch.items()}
+    R, t = model(data)
+    n = 51 * 91
+    assert data["kps0_shape"] == [51, 91] and data["scores"].shape == (1, n, n) and data["dsc0"].shape == (1, 128, n)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(data["final_scores"]).all()
+    ref = O.sinkhorn(data["dsc0"].cpu(), data["dsc1"].cpu(), 1.0, 10)
+    assert rel(data["scores"], ref) < 5e-5
+    kp = torch.matmul(data["scr0"].cpu().transpose(2, 1), data["scr1"].cpu())
+    assert torch.equal(data["kp_scores"].cpu(), kp) and rel(data["final_scores"], ref * kp) < 5e-5

@@ -1,0 +1,25 @@
+"""GEMM tile-schedule A/B on the encoder shapes (dev tool).  python tools/bench_gemm.py [tiles...]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mickey_amd import ops  # noqa: E402
+from tools.bench_kernels import timeit  # noqa: E402
+
+tiles = [int(t) for t in sys.argv[1:]] or [2, 3, 5]
+dev = torch.device("cuda:0")
+for M in (3878 * 8, 3878 * 32):
+    for (N, K, name) in ((3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc1"), (1024, 4096, "fc2")):
+        a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
+        w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
+        out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+        row = []
+        for tile in tiles:
+            ops.gemm_set_tile(tile)
+            t = timeit(lambda: ops.gemm(a, w, None, out=out))
+            row.append("tile%d %7.1f TF" % (tile, 2.0 * M * N * K / t / 1e12))
+        ops.gemm_set_tile(0)
+        print("M=%6d %-4s " % (M, name) + "  ".join(row), flush=True)

@@ -1,10 +1,7 @@
 #!/bin/bash
+# one GPU visit: pp64 GEMM correctness + A/B
 mkdir -p gpurun_out
-for i in 1 2; do
-for t in 0 4; do
-  echo "gemm-tile $t:" $(python bench.py --steps 4 --warmup 2 --no-cpu-baseline --gemm-tile $t 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['achieved'])")
-done
-done
-for a in 2 4; do
-  echo "attn-mode $a:" $(python bench.py --steps 4 --warmup 2 --no-cpu-baseline --attn-mode $a 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'])")
-done
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm or conv3x3" 2>&1 | tail -5
+timeout 300 python tools/bench_gemm.py 2 3 5 2>&1 | tail -10
+timeout 200 python bench.py --no-cpu-baseline --gemm-tile 6 2>&1 | tail -1
+timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1
