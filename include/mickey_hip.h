@@ -44,8 +44,11 @@ const char* mk_last_error(void);
 int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldc, int M, int N, int K,
             int act, int out_is_f32, int dtype, mk_stream_t stream);
 
-/* Tile selection of the GEMM/conv kernel: 0 = automatic (by problem size), 1 = force 128x128, 2 = force
- * 256x256.  Process-wide; for benchmarks and tests. */
+/* Schedule selection of the GEMM/conv kernel: 0 = automatic (128x128 two-stage for small problems, the 256x256
+ * full-line ping-pong schedule for large ones), 1 = force 128x128, 2 = force the 256x256 persistent K-stream kernel,
+ * 3 = force the K=32 ping-pong ring, 4 = automatic with schedule 2 for large problems, 5/7/8/9 = full-line
+ * ping-pong variants (persistent / banded tile order on or off), 10..21 = timing ablations (wrong results).
+ * Process-wide; for benchmarks and tests. */
 int mk_gemm_set_tile(int mode);
 
 /* `groups` independent GEMMs of identical shape in one launch (element strides per group; a stride

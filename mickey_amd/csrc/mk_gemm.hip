@@ -566,9 +566,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 //   * A_g(kt+2) is issued in row g's C(kt,1) slot (its last reader, L(kt,1) of the same row, is one barrier behind);
 //     W(kt+1) is issued in row g's L(kt,0) slot (the last reader of W(kt-1), row 1 in slot 4kt-1, is behind);
 //   * every DMA has 3-5 slots to land; once per stage a counted vmcnt at the end of slot 4kt+3 (row 0: 4 newer DMAs
-//     may stay in flight; row 1: 0) precedes the barrier that opens stage kt+1.
-template <typename T, int AMODE>
-__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
+//     may stay in flight; row 1: 0) precedes the barrier that opens stage kt+1.  (Epilogue stores also count in
+//     vmcnt; loads return in order among themselves, so "<= 4 outstanding" still implies the older DMAs landed.)
+// Persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... and the K stages of successive tiles form ONE stream
+// (stage parity carries over), so the first stages of the next tile are in flight during the epilogue, which both
+// wave-rows run in the slot that opens the next tile.  Tile order: bands of PP_GM m-tiles walked n-major, so the 32
+// tiles an XCD works on at one time form an 8 x 4 block of the output (A and W panels shared in its L2).
+__device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_GM, int& tm, int& tn) {
+  const int band = id / (PP_GM * ntn);
+  const int rem = id - band * (PP_GM * ntn);
+  const int gm = min(PP_GM, ntm - band * PP_GM);
+  tm = band * PP_GM + rem % gm;
+  tn = rem / gm;
+}
+
+template <typename T, int AMODE, bool PERSIST>
+__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
   using V8 = typename Lp<T>::V8;
   constexpr int WMF = 8, BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;   // 64 KiB per stage
@@ -580,49 +593,56 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int g = blockIdx.y;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  const int id = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+  const int ntiles = ntm * ntn;
+  const int nk = p.K / BK;
 
   const T* A = (const T*)p.A + (long long)g * p.strideA_g;
   const T* A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
   const T* W = (const T*)p.W + (long long)g * p.strideW_g;
   const int srow = lane >> 3, sp = lane & 7;
-  // this wave's 4 A pieces (own half) and 4 W pieces; piece = 8 rows
+  // this wave's 4 A pieces (own half) and 4 W pieces of a stage; piece = 8 rows x 128 B
   const T* wrow[4];
   long long aoff[4];
   int ay[4], ax[4];
   bool avalid[4];
+  auto set_w = [&](int n0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rw = (wave * 4 + j) * 8 + srow;
-    int n = n0 + rw;
-    n = n < p.N ? n : p.N - 1;
-    wrow[j] = W + (long long)n * p.ldw + swz8(rw, sp) * 8;
-    const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
-    int m = m0 + ra;
-    avalid[j] = m < p.M;
-    m = avalid[j] ? m : p.M - 1;
-    if (AMODE == A_DENSE) {
-      aoff[j] = (long long)m * p.lda + swz8(ra, sp) * 8;
-      ay[j] = ax[j] = 0;
-    } else {
-      const int pix = m % (p.H * p.Wd);
-      ay[j] = pix / p.Wd;
-      ax[j] = pix % p.Wd;
-      aoff[j] = m;
+    for (int j = 0; j < 4; ++j) {
+      const int rw = (wave * 4 + j) * 8 + srow;
+      int n = n0 + rw;
+      n = n < p.N ? n : p.N - 1;
+      wrow[j] = W + (long long)n * p.ldw + swz8(rw, sp) * 8;
     }
-  }
-  const int nk = p.K / BK;
-  auto dma_w = [&](int kt) {   // 4 instructions
-    if (kt >= nk) return;
-    char* sW = smem + (kt & 1) * STAGE_BYTES + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(wrow[j] + kt * BK, sW + (wave * 4 + j) * 1024);
   };
-  auto dma_a = [&](int kt) {   // 4 instructions
-    if (kt >= nk) return;
-    char* sA = smem + (kt & 1) * STAGE_BYTES;
-    const int k0 = kt * BK;
+  auto set_a = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
+      int m = m0 + ra;
+      avalid[j] = m < p.M;
+      m = avalid[j] ? m : p.M - 1;
+      if (AMODE == A_DENSE) {
+        aoff[j] = (long long)m * p.lda + swz8(ra, sp) * 8;
+      } else {
+        const int pix = m % (p.H * p.Wd);
+        ay[j] = pix / p.Wd;
+        ax[j] = pix % p.Wd;
+        aoff[j] = m;
+      }
+    }
+  };
+  // s = stage index relative to the current tile; s >= nk addresses the next tile (registers already switched)
+  auto dma_w = [&](int s, int pb, bool more) {   // 4 instructions
+    if (s >= nk && !more) return;
+    char* sW = smem + ((pb + s) & 1) * STAGE_BYTES + A_BYTES;
+    const int k0 = (s < nk ? s : s - nk) * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(wrow[j] + k0, sW + (wave * 4 + j) * 1024);
+  };
+  auto dma_a = [&](int s, int pb, bool more) {   // 4 instructions
+    if (s >= nk && !more) return;
+    char* sA = smem + ((pb + s) & 1) * STAGE_BYTES;
+    const int k0 = (s < nk ? s : s - nk) * BK;
     if (AMODE == A_DENSE) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) glds16(A + aoff[j] + k0, sA + (wm * 16 + wn * 4 + j) * 1024);
@@ -654,15 +674,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }
   };
 
-  f32x4 acc[WMF][4];
-#pragma unroll
-  for (int i = 0; i < WMF; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  V8 wf[4], xf[WMF];
   const int fr = lane & 15, fg = lane >> 4;
-  auto load_frags = [&](int kt, int h) {
-    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+  auto load_frags = [&](V8* wf, V8* xf, int par, int h) {
+    const char* sA = smem + par * STAGE_BYTES;
     const char* sW = sA + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -675,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, h * 4 + fg) * 16);
     }
   };
-  auto mfma32 = [&]() {
+  auto mfma32 = [&](f32x4 (*acc)[4], const V8* wf, const V8* xf) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < WMF; ++mi)
@@ -688,66 +702,80 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
   };
 
+  int seq = blockIdx.x;
+  int tm, tn;
+  pp_tile_coords(xcd_remap(seq, ntiles), ntm, ntn, band_m, tm, tn);
+  int m0 = tm * BM, n0 = tn * BN;
+  set_a(m0);
+  set_w(n0);
   // prologue: stage 0 (own A half + W share) and the own A half of stage 1
-  dma_a(0);
-  dma_w(0);
-  dma_a(1);
-  if (nk > 1)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wm == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      bar();                      // slot 4kt
-      load_frags(kt, 0);
-      dma_w(kt + 1);
-      bar();                      // slot 4kt+1
-      mfma32();
-      bar();                      // slot 4kt+2
-      load_frags(kt, 1);
-      bar();                      // slot 4kt+3
-      mfma32();
-      dma_a(kt + 2);
-      if (kt + 2 < nk)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  dma_a(0, 0, false);
+  dma_w(0, 0, false);
+  dma_a(1, 0, false);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  int pb = 0;   // LDS stage parity of the current tile's stage 0
+  if (wm == 1) bar();   // slot 0: this wave-row idles
+  bool skipbar = false;
+  for (;;) {
+    f32x4 acc[WMF][4];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    V8 wf[4], xf[WMF];
+    const int nseq = seq + gridDim.x;
+    const bool more = PERSIST && nseq < ntiles;
+    int nm0 = 0, nn0 = 0;
+    if (more) {
+      pp_tile_coords(xcd_remap(nseq, ntiles), ntm, ntn, band_m, tm, tn);
+      nm0 = tm * BM;
+      nn0 = tn * BN;
     }
-  } else {
-    bar();                        // slot 0: this wave-row idles
-    for (int kt = 0; kt < nk; ++kt) {
-      bar();                      // slot 4kt+1
-      load_frags(kt, 0);
-      dma_w(kt + 1);
-      bar();                      // slot 4kt+2
-      mfma32();
-      bar();                      // slot 4kt+3
-      load_frags(kt, 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
-      if (kt + 1 < nk) bar();     // slot 4kt+4
-      mfma32();
-      dma_a(kt + 2);
+    if (wm == 0) {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (more && kt == nk - 2) set_a(nm0);   // A DMAs from here on belong to the next tile
+        if (more && kt == nk - 1) set_w(nn0);
+        if (!(kt == 0 && skipbar)) bar();   // slot 4kt
+        load_frags(wf, xf, (pb + kt) & 1, 0);
+        dma_w(kt + 1, pb, more);
+        bar();                      // slot 4kt+1
+        mfma32(acc, wf, xf);
+        bar();                      // slot 4kt+2
+        load_frags(wf, xf, (pb + kt) & 1, 1);
+        bar();                      // slot 4kt+3
+        mfma32(acc, wf, xf);
+        dma_a(kt + 2, pb, more);
+        if (kt + 2 < nk || more)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (more) bar();              // opens slot 0 of the next tile (row 1 runs its last C slot there)
+      skipbar = true;
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (more && kt == nk - 2) set_a(nm0);
+        if (more && kt == nk - 1) set_w(nn0);
+        bar();                      // slot 4kt+1
+        load_frags(wf, xf, (pb + kt) & 1, 0);
+        dma_w(kt + 1, pb, more);
+        bar();                      // slot 4kt+2
+        mfma32(acc, wf, xf);
+        bar();                      // slot 4kt+3
+        load_frags(wf, xf, (pb + kt) & 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
+        if (kt + 1 < nk || more) bar();   // slot 4kt+4
+        mfma32(acc, wf, xf);
+        dma_a(kt + 2, pb, more);
+      }
     }
+    epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+    if (!more) break;
+    seq = nseq;
+    m0 = nm0;
+    n0 = nn0;
+    pb = (pb + nk) & 1;
   }
-  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
-}
-
-template <typename T, int AMODE>
-int launch_pp64(const GemmParams& p, int groups, hipStream_t st) {
-  constexpr int LDS = 2 * 512 * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
-      return MK_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p);
-  MK_CHECK_LAUNCH();
-  return MK_OK;
 }
 
 int g_num_cus = 0;
@@ -759,6 +787,26 @@ int num_cus() {
     g_num_cus = n;
   }
   return g_num_cus;
+}
+
+template <typename T, int AMODE, bool PERSIST>
+int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
+  constexpr int LDS = 2 * 512 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MK_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  const int cap = (num_cus() + groups - 1) / groups;   // one resident workgroup per CU in total
+  const int gx = (!PERSIST || ntm * ntn < cap) ? ntm * ntn : cap;
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, PERSIST>), dim3(gx, groups, 1), dim3(512), LDS, st, p, band_m);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
 }
 
 template <typename T, int AMODE, int WMF, int NWM, int NWN>
@@ -805,7 +853,8 @@ int launch_pp(const GemmParams& p, int groups, hipStream_t st) {
   return MK_OK;
 }
 
-int g_force_tile = 0;  // 0 auto, 1 force 128x128, 2 force 256x256, 3 force ping-pong, 4 auto with ping-pong for large problems
+int g_force_tile = 0;  // 0 auto (128x128 or full-line ping-pong), 1 force 128x128, 2 force 256x256 K-stream, 3 force K=32 ping-pong ring,
+                       // 4 auto with the 256x256 K-stream kernel for large problems, 5/7/8/9 full-line ping-pong variants, 10+ ablations
 
 template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
@@ -814,9 +863,20 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
   if (g_force_tile == 1) big = false;
   if (g_force_tile == 2) big = true;
-  if (g_force_tile == 5 || (g_force_tile == 6 && big))
-    return dtype == MK_BF16 ? launch_pp64<__bf16, AMODE>(p, groups, st) : launch_pp64<_Float16, AMODE>(p, groups, st);
-  if (g_force_tile == 3 || (g_force_tile == 4 && big))
+  const bool k_ok = p.K >= 2 * BK;
+  const bool forced64 = g_force_tile == 5 || (g_force_tile >= 7 && g_force_tile <= 9);
+  if (k_ok && (forced64 || ((g_force_tile == 0 || g_force_tile == 6) && big))) {
+    // auto (0/6) and 7: one tile per workgroup, bands of 8 m-tiles (measured best: 6-16 % over the K=32 ring and the
+    // K-stream kernel, 8-10 % over its own persistent variant); 5: persistent + bands; 8: persistent, row-major; 9: neither
+    const bool persist = g_force_tile == 5 || g_force_tile == 8;
+    const int band_m = (g_force_tile == 8 || g_force_tile == 9) ? 1 : 8;
+    if (persist)
+      return dtype == MK_BF16 ? launch_pp64<__bf16, AMODE, true>(p, groups, st, band_m)
+                              : launch_pp64<_Float16, AMODE, true>(p, groups, st, band_m);
+    return dtype == MK_BF16 ? launch_pp64<__bf16, AMODE, false>(p, groups, st, band_m)
+                            : launch_pp64<_Float16, AMODE, false>(p, groups, st, band_m);
+  }
+  if (g_force_tile == 3)
     return dtype == MK_BF16 ? launch_pp<__bf16, AMODE>(p, groups, st) : launch_pp<_Float16, AMODE>(p, groups, st);
   if (g_force_tile >= 10 && g_force_tile < 22 && AMODE == A_DENSE && dtype == MK_BF16) {  // timing ablations (wrong results)
     switch (g_force_tile - 10) {
@@ -854,7 +914,7 @@ int check_common(const GemmParams& p, int dtype) {
 extern "C" {
 
 int mk_gemm_set_tile(int mode) {
-  MK_CHECK_ARG((mode >= 0 && mode <= 6) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
+  MK_CHECK_ARG((mode >= 0 && mode <= 9) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
   g_force_tile = mode;
   return MK_OK;
 }

@@ -34,7 +34,7 @@ def _auto_tile():
         ops.attn_set_mode(0)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])
 def test_gemm_bias_act(dtype, M, N, K, tile):
@@ -72,7 +72,7 @@ def test_gemm_ls_residual():
     assert rel(xd, ref) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 7])
 def test_gemm_qkv_layout(tile):
     from mickey_amd import ops
     dev = _dev()
@@ -172,7 +172,7 @@ def test_flash_attention(dtype, ntok, nimg, heads, mode):
     assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("with_sc,with_res", [(False, False), (True, False), (False, True)])
 def test_conv3x3(with_sc, with_res, tile):
     from mickey_amd import ops

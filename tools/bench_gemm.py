@@ -1,6 +1,8 @@
-"""GEMM tile-schedule A/B on the encoder shapes (dev tool).  python tools/bench_gemm.py [tiles...]"""
+"""GEMM tile-schedule A/B on the encoder shapes (dev tool).  python tools/bench_gemm.py [tiles...]
+Repetitions are interleaved over the schedules and the median is reported (clock / power drift on one box is a few %)."""
 import math
 import os
+import statistics
 import sys
 
 import torch
@@ -16,10 +18,10 @@ for M in (3878 * 8, 3878 * 32):
         a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
         w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
         out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-        row = []
-        for tile in tiles:
-            ops.gemm_set_tile(tile)
-            t = timeit(lambda: ops.gemm(a, w, None, out=out))
-            row.append("tile%d %7.1f TF" % (tile, 2.0 * M * N * K / t / 1e12))
+        ts = {t: [] for t in tiles}
+        for rep in range(5):
+            for tile in (tiles if rep % 2 == 0 else tiles[::-1]):
+                ops.gemm_set_tile(tile)
+                ts[tile].append(timeit(lambda: ops.gemm(a, w, None, out=out), iters=10, warm=2))
         ops.gemm_set_tile(0)
-        print("M=%6d %-4s " % (M, name) + "  ".join(row), flush=True)
+        print("M=%6d %-4s " % (M, name) + "  ".join("tile%d %7.1f TF" % (t, 2.0 * M * N * K / statistics.median(ts[t]) / 1e12) for t in tiles), flush=True)

@@ -1,7 +1,11 @@
 #!/bin/bash
-# one GPU visit: pp64 GEMM correctness + A/B
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm or conv3x3" 2>&1 | tail -5
-timeout 300 python tools/bench_gemm.py 2 3 5 2>&1 | tail -10
-timeout 200 python bench.py --no-cpu-baseline --gemm-tile 6 2>&1 | tail -1
-timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -4
+timeout 200 python bench.py --no-cpu-baseline --gemm-tile 4 2>&1 | tail -1 > gpurun_out/bench_tile4.json
+timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_tile0.json
+timeout 200 python bench.py --no-cpu-baseline --gemm-tile 4 2>&1 | tail -1 > gpurun_out/bench_tile4b.json
+timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_tile0b.json
+for f in tile4 tile0 tile4b tile0b; do python - <<PY
+import json; d=json.load(open("gpurun_out/bench_$f.json")); print("$f", round(d["value"],1), "pairs/s", round(d["roofline"]["achieved"],1), "TF")
+PY
+done
