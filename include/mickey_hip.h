@@ -51,6 +51,11 @@ int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, v
  * Process-wide; for benchmarks and tests. */
 int mk_gemm_set_tile(int mode);
 
+/* Profiling hook (dev): while `buf` is non-null, bf16 dense launches of the full-line ping-pong schedule write 6
+ * uint64 per (tile, wave-row): entry / first-stage-landed / K-loop-done / epilogue-issued on the 100 MHz wall clock,
+ * HW_ID, XCC_ID.  buf must hold tiles*2*6 values.  Pass null to switch off. */
+int mk_gemm_debug_timeline(void* buf);
+
 /* `groups` independent GEMMs of identical shape in one launch (element strides per group; a stride
  * of 0 shares the operand).  Used to run the four heads side by side. */
 int mk_gemm_grouped(const void* A, int lda, long long strideA, const void* W, int ldw, long long strideW, const float* bias,

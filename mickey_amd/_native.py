@@ -22,6 +22,7 @@ SIGNATURES = {
     "mk_last_error": ("s", ""),
     "mk_gemm": ("i", "pipippiiiiiiip"),
     "mk_gemm_set_tile": ("i", "i"),
+    "mk_gemm_debug_timeline": ("i", "p"),
     "mk_gemm_grouped": ("i", "pilpilplpiliiiiiiip"),
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
     "mk_gemm_qkv": ("i", "pipippppiiiifip"),

@@ -192,8 +192,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (ACT == MK_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          v = gelu_erf4(v);
         }
         if (p.out_f32) {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = v;
@@ -556,6 +555,206 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue of the full-line ping-pong kernel.  In the accumulator layout a lane owns 4 features of one
+// row, so a direct store instruction touches 16 rows x 32 B -- measured ~65 cycles per instruction and 4.4-7.2 us
+// per 256x256 tile (13-21 % of a K = 1024 tile).  After the K loop the 128-KiB ring is idle: each wave bounces its
+// 128x64 block through a private 16-KiB slice (wave-local, LDS is in-order per wave: no barrier) and then moves whole
+// rows: 16-bit outputs 16 B per lane = 8 full 128-byte lines per instruction, fp32 outputs (two 64-row halves) 4 x
+// 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
+// only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
+// XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
+template <typename T, int EPI, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
+                                                  int wn, int lane, int g) {
+  using V4 = typename Lp<T>::V4;
+  using V8 = typename Lp<T>::V8;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const int nw = n0 + wn * 64;        // first feature of this wave's block
+  const int mw = m0 + wm * 128;       // first row
+  f32x4 bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nw + fg * 4 + ni * 16;
+    bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32);
+  if (lp_out) {
+    int which = 0, head = 0;
+    if (EPI == MK_EPI_QKV) {
+      const int D = p.heads * 64;
+      which = nw / D;
+      head = (nw - which * D) >> 6;
+      if (which == 2) {   // V^T, key-permuted: element stores straight from the accumulators
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = mw + mi * 16 + fr;
+          if (m >= p.M) continue;
+          const int img = m / p.ntok, tok = m - img * p.ntok;
+          const long long hb = (long long)img * p.heads + head;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni] + bv[ni];
+            T* dst = (T*)p.vt + (hb * 64 + ni * 16 + fg * 4) * p.ntok_pad + vperm(tok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
+          }
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int r = mi * 16 + fr;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[mi][ni];
+        if (HAS_BIAS) v += bv[ni];
+        if (EPI == MK_EPI_QKV) {
+          if (which == 0) v *= p.qscale;
+        } else {
+          if (p.resid_lp) {
+            const int m = mw + r, n = nw + fg * 4 + ni * 16;
+            if (m < p.M && n < p.N) {
+              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+            }
+          }
+          if (ACT == MK_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (ACT == MK_ACT_GELU) {
+            v = gelu_erf4(v);
+          }
+        }
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+        const int c = ni * 2 + (fg >> 1);
+        *(V4*)(wl + r * 128 + ((c ^ (r & 7)) << 4) + (fg & 1) * 8) = o;
+      }
+    }
+    const int rr = lane >> 3, c = lane & 7;
+    const int n = nw + c * 8;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 8 + rr;
+      const int m = mw + r;
+      const V8 val = *(const V8*)(wl + r * 128 + ((c ^ (r & 7)) << 4));
+      if (m >= p.M || n >= p.N) continue;
+      T* dst;
+      if (EPI == MK_EPI_QKV) {
+        const int img = m / p.ntok, tok = m - img * p.ntok;
+        dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
+      } else {
+        dst = (T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n;
+      }
+      if (n + 8 <= p.N) {
+        *(V8*)dst = val;
+      } else {   // N % 8 == 4: the last chunk is half wide
+        V4 lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = val[e];
+        *(V4*)dst = lo;
+      }
+    }
+  } else {
+    const int rr = lane >> 4, c = lane & 15;
+    const int n = nw + c * 4;
+    f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == MK_EPI_LS_RESIDUAL && n < p.N) gm = *(const f32x4*)(p.gamma + n);
+    // read-modify-write of the residual stream: all 16 loads of a half are issued before anything waits on them (one
+    // HBM round trip per half instead of one per row group: measured 0.68 us per dependent load -> 22 us per tile);
+    // the second half's loads go out while the first half is still being stored
+    f32x4 xr[2][16];
+    auto preload = [&](int half) {
+      if (EPI != MK_EPI_LS_RESIDUAL) return;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = mw + half * 64 + it * 4 + rr;
+        xr[half][it] = (m < p.M && n < p.N) ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto stage = [&](int half) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int r = mi * 16 + fr;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4 v = acc[half * 4 + mi][ni];
+          if (HAS_BIAS) v += bv[ni];
+          if (EPI == MK_EPI_STORE) {
+            if (p.resid_lp) {
+              const int m = mw + half * 64 + r, nn = nw + fg * 4 + ni * 16;
+              if (m < p.M && nn < p.N) {
+                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + nn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+              }
+            }
+            if (ACT == MK_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (ACT == MK_ACT_GELU) {
+              v = gelu_erf4(v);
+            }
+          }
+          const int cw = ni * 4 + fg;
+          *(f32x4*)(wl + r * 256 + ((cw ^ (r & 15)) << 4)) = v;
+        }
+      }
+    };
+    auto drain = [&](int half) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 4 + rr;
+        const int m = mw + half * 64 + r;
+        const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
+        if (m >= p.M || n >= p.N) continue;
+        if (EPI == MK_EPI_LS_RESIDUAL) {
+          f32x4 x = xr[half][it];
+          x += gm * val;
+          *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+        } else if (EPI == MK_EPI_PATCH) {
+          const int img = m / p.npatch, tok = m - img * p.npatch;
+          const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+          *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = val + pe;
+        } else {
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
+        }
+      }
+    };
+    preload(0);
+    stage(0);
+    preload(1);
+    drain(0);
+    stage(1);
+    drain(1);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
+                                             int lane, int g) {
+  switch (p.epi) {   // wave-uniform, once per output tile
+    case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    default:
+      if (!p.bias) {
+        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      } else {
+        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Ping-pong with FULL-LINE LDS-DMA pieces: 256x256 tile, 8 waves (wave-row g = wave>>2), LDS stages of K = 64
 // (128-byte rows, the swz8 swizzle of the plain kernel), computed in two K = 32 sub-steps h.  A piece is 8 rows x
 // 128 B (8 full cache lines; the K = 32 ring above moves 16 half lines per piece, measured 12 % slower).  Only two
@@ -580,8 +779,19 @@ __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_
   tn = rem / gm;
 }
 
-template <typename T, int AMODE, bool PERSIST>
-__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
+// DBG: dev-only instantiation that records per wave-row {entry, first stage landed, K loop done, epilogue issued}
+// on the 100-MHz wall clock plus HW_ID / XCC_ID of the first tile a workgroup runs (tools/gemm_timeline.py)
+template <typename T, int AMODE, bool PERSIST, bool DBG = false>
+__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m, int stagger, unsigned long long* dbg) {
+  unsigned long long t_entry = 0, t_landed = 0, t_loop = 0;
+  if (DBG) t_entry = __builtin_amdgcn_s_memrealtime();
+  // All CUs start together and would hit their (HBM-heavy, un-overlapped) epilogues in lockstep while HBM idles during
+  // the K loops.  Spreading the first round of workgroups over `stagger` ticks of the 100-MHz clock de-phases them.
+  if (stagger > 0 && blockIdx.x < 256) {
+    const unsigned h = (blockIdx.x * 2654435761u) >> 24;
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + ((unsigned long long)h * stagger >> 8);
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+  }
   using V8 = typename Lp<T>::V8;
   constexpr int WMF = 8, BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;   // 64 KiB per stage
@@ -713,6 +923,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   dma_w(0, 0, false);
   dma_a(1, 0, false);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (DBG) t_landed = __builtin_amdgcn_s_memrealtime();
   int pb = 0;   // LDS stage parity of the current tile's stage 0
   if (wm == 1) bar();   // slot 0: this wave-row idles
   bool skipbar = false;
@@ -750,7 +961,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (more) bar();              // opens slot 0 of the next tile (row 1 runs its last C slot there)
+      if (more || !PERSIST) bar();  // opens slot 0 of the next tile (row 1 runs its last C slot there); without
+                                    // persistence: row 1's last fragment reads are done, the LDS ring is free
       skipbar = true;
     } else {
       for (int kt = 0; kt < nk; ++kt) {
@@ -764,12 +976,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
         bar();                      // slot 4kt+3
         load_frags(wf, xf, (pb + kt) & 1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
-        if (kt + 1 < nk || more) bar();   // slot 4kt+4
+        if (kt + 1 < nk || more || !PERSIST) bar();   // slot 4kt+4
         mfma32(acc, wf, xf);
         dma_a(kt + 2, pb, more);
       }
     }
-    epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+    if (DBG) t_loop = __builtin_amdgcn_s_memrealtime();
+    if (PERSIST)   // the ring already holds the next tile's first stages
+      epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+    else
+      epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g);
+    if (DBG && wn == 0 && lane == 0) {
+      unsigned long long* d = dbg + ((long long)seq * 2 + wm) * 6;
+      d[0] = t_entry;
+      d[1] = t_landed;
+      d[2] = t_loop;
+      d[3] = __builtin_amdgcn_s_memrealtime();
+      d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+      d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+      t_entry = d[3];
+    }
     if (!more) break;
     seq = nseq;
     m0 = nm0;
@@ -789,12 +1015,15 @@ int num_cus() {
   return g_num_cus;
 }
 
-template <typename T, int AMODE, bool PERSIST>
+unsigned long long* g_dbg = nullptr;   // mk_gemm_debug_timeline
+int g_stagger_us = 0;                  // start-time spread of the first workgroup round for RMW epilogues (set_tile 100+us)
+
+template <typename T, int AMODE, bool PERSIST, bool DBG = false>
 int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   constexpr int LDS = 2 * 512 * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -804,7 +1033,8 @@ int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
   const int cap = (num_cus() + groups - 1) / groups;   // one resident workgroup per CU in total
   const int gx = (!PERSIST || ntm * ntn < cap) ? ntm * ntn : cap;
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, PERSIST>), dim3(gx, groups, 1), dim3(512), LDS, st, p, band_m);
+  const int stagger = (p.epi == MK_EPI_LS_RESIDUAL && ntm * ntn >= 4 * cap) ? g_stagger_us * 100 : 0;
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, PERSIST, DBG>), dim3(gx, groups, 1), dim3(512), LDS, st, p, band_m, stagger, g_dbg);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -870,6 +1100,9 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
     // K-stream kernel, 8-10 % over its own persistent variant); 5: persistent + bands; 8: persistent, row-major; 9: neither
     const bool persist = g_force_tile == 5 || g_force_tile == 8;
     const int band_m = (g_force_tile == 8 || g_force_tile == 9) ? 1 : 8;
+    if (g_dbg && AMODE == A_DENSE && dtype == MK_BF16 && groups == 1)
+      return persist ? launch_pp64<__bf16, A_DENSE, true, true>(p, groups, st, band_m)
+                     : launch_pp64<__bf16, A_DENSE, false, true>(p, groups, st, band_m);
     if (persist)
       return dtype == MK_BF16 ? launch_pp64<__bf16, AMODE, true>(p, groups, st, band_m)
                               : launch_pp64<_Float16, AMODE, true>(p, groups, st, band_m);
@@ -913,7 +1146,16 @@ int check_common(const GemmParams& p, int dtype) {
 
 extern "C" {
 
+int mk_gemm_debug_timeline(void* buf) {
+  g_dbg = (unsigned long long*)buf;
+  return MK_OK;
+}
+
 int mk_gemm_set_tile(int mode) {
+  if (mode >= 100 && mode < 400) {   // dev: stagger window in microseconds
+    g_stagger_us = mode - 100;
+    return MK_OK;
+  }
   MK_CHECK_ARG((mode >= 0 && mode <= 9) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
   g_force_tile = mode;
   return MK_OK;

@@ -23,6 +23,11 @@ def gemm_set_tile(mode):
     call("mk_gemm_set_tile", int(mode))
 
 
+def gemm_debug_timeline(buf):
+    """Dev hook: int64 CUDA tensor of tiles*12 values receiving the per-tile timeline, or None to switch off."""
+    call("mk_gemm_debug_timeline", buf.data_ptr() if buf is not None else None)
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, out_f32=False, out=None, lda=None, K=None):
     """out = act(a[:, :K] @ w[:, :K].T + bias).  a [M, lda] lp, w [N, ldw] lp."""
     M = a.shape[0]

@@ -14,7 +14,8 @@ q = torch.zeros((nimg, 16, pad, 64), device=dev, dtype=torch.bfloat16); k = torc
 vt = torch.zeros((nimg, 16, 64, pad), device=dev, dtype=torch.bfloat16)
 out3 = torch.empty((M, 3 * D), device=dev, dtype=torch.bfloat16); out4 = torch.empty((M, 4 * D), device=dev, dtype=torch.bfloat16)
 out1 = torch.empty((M, D), device=dev, dtype=torch.bfloat16)
-for tile in (1, 2, 3):
+for tile, stag in ((2, 0), (7, 0), (7, 30)):
+    ops.gemm_set_tile(100 + stag)
     ops.gemm_set_tile(tile)
     r = {}
     r["qkv plain"] = timeit(lambda: ops.gemm(y, wq, None, out=out3))
@@ -26,4 +27,4 @@ for tile in (1, 2, 3):
     r["fc2 ls_resid"] = timeit(lambda: ops.gemm_ls_residual(hid, w2, b2, g, x))
     r["proj plain"] = timeit(lambda: ops.gemm(y, wp, None, out=out1))
     r["proj ls_resid"] = timeit(lambda: ops.gemm_ls_residual(y, wp, bp, g, x))
-    print("tile", tile, {k_: "%.3f ms" % (v * 1e3) for k_, v in r.items()}, flush=True)
+    print("tile", tile, "stagger", stag, {k_: "%.3f ms" % (v * 1e3) for k_, v in r.items()}, flush=True)
