@@ -734,6 +734,190 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
   }
 }
 
+// Same staging through a 4-KiB slice per wave (the 32 KiB of LDS beside the 128-KiB ring): for the persistent variant,
+// whose ring already holds the first stages of the next tile while the epilogue runs.  16-bit outputs go in 4 passes
+// of 32 rows, fp32 outputs in 8 passes of 16 rows; LDS executes a wave's accesses in order, so pass q+1 may overwrite
+// the slice as soon as pass q's reads are issued.
+template <typename T, int EPI, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_lds4k_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
+                                                    int wn, int lane, int g) {
+  using V4 = typename Lp<T>::V4;
+  using V8 = typename Lp<T>::V8;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const int nw = n0 + wn * 64;
+  const int mw = m0 + wm * 128;
+  f32x4 bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nw + fg * 4 + ni * 16;
+    bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32);
+  if (lp_out) {
+    int which = 0, head = 0;
+    if (EPI == MK_EPI_QKV) {
+      const int D = p.heads * 64;
+      which = nw / D;
+      head = (nw - which * D) >> 6;
+      if (which == 2) {   // V^T, key-permuted: element stores straight from the accumulators
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = mw + mi * 16 + fr;
+          if (m >= p.M) continue;
+          const int img = m / p.ntok, tok = m - img * p.ntok;
+          const long long hb = (long long)img * p.heads + head;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni] + bv[ni];
+            T* dst = (T*)p.vt + (hb * 64 + ni * 16 + fg * 4) * p.ntok_pad + vperm(tok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
+          }
+        }
+        return;
+      }
+    }
+    const int rr = lane >> 3, c = lane & 7;
+    const int n = nw + c * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int mi = q * 2 + mh;
+        const int r = mh * 16 + fr;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4 v = acc[mi][ni];
+          if (HAS_BIAS) v += bv[ni];
+          if (EPI == MK_EPI_QKV) {
+            if (which == 0) v *= p.qscale;
+          } else {
+            if (p.resid_lp) {
+              const int m = mw + q * 32 + r, nn = nw + fg * 4 + ni * 16;
+              if (m < p.M && nn < p.N) {
+                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + nn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+              }
+            }
+            if (ACT == MK_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (ACT == MK_ACT_GELU) {
+              v = gelu_erf4(v);
+            }
+          }
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          const int cc = ni * 2 + (fg >> 1);
+          *(V4*)(wl + r * 128 + ((cc ^ (r & 7)) << 4) + (fg & 1) * 8) = o;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + rr;
+        const int m = mw + q * 32 + r;
+        const V8 val = *(const V8*)(wl + r * 128 + ((c ^ (r & 7)) << 4));
+        if (m >= p.M || n >= p.N) continue;
+        T* dst;
+        if (EPI == MK_EPI_QKV) {
+          const int img = m / p.ntok, tok = m - img * p.ntok;
+          dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
+        } else {
+          dst = (T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n;
+        }
+        if (n + 8 <= p.N) {
+          *(V8*)dst = val;
+        } else {
+          V4 lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = val[e];
+          *(V4*)dst = lo;
+        }
+      }
+    }
+  } else {
+    const int rr = lane >> 4, c = lane & 15;
+    const int n = nw + c * 4;
+    f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == MK_EPI_LS_RESIDUAL && n < p.N) gm = *(const f32x4*)(p.gamma + n);
+    f32x4 xr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (EPI == MK_EPI_LS_RESIDUAL && (q & 1) == 0) {   // the 8 row groups of these 32 rows in one round trip
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = mw + q * 16 + j * 4 + rr;
+          xr[j] = (m < p.M && n < p.N) ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[q][ni];
+        if (HAS_BIAS) v += bv[ni];
+        if (EPI == MK_EPI_STORE) {
+          if (p.resid_lp) {
+            const int m = mw + q * 16 + fr, nn = nw + fg * 4 + ni * 16;
+            if (m < p.M && nn < p.N) {
+              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + nn);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+            }
+          }
+          if (ACT == MK_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (ACT == MK_ACT_GELU) {
+            v = gelu_erf4(v);
+          }
+        }
+        const int cw = ni * 4 + fg;
+        *(f32x4*)(wl + fr * 256 + ((cw ^ fr) << 4)) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + rr;
+        const int m = mw + q * 16 + r;
+        const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ r) << 4));
+        if (m >= p.M || n >= p.N) continue;
+        if (EPI == MK_EPI_LS_RESIDUAL) {
+          f32x4 x = xr[(q & 1) * 4 + it];
+          x += gm * val;
+          *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+        } else if (EPI == MK_EPI_PATCH) {
+          const int img = m / p.npatch, tok = m - img * p.npatch;
+          const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+          *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = val + pe;
+        } else {
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_lds4k(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
+                                               int lane, int g) {
+  switch (p.epi) {   // wave-uniform, once per output tile
+    case MK_EPI_LS_RESIDUAL: epilogue_lds4k_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_QKV: epilogue_lds4k_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_PATCH: epilogue_lds4k_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    default:
+      if (!p.bias) {
+        if (p.act == MK_ACT_RELU) epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      } else {
+        if (p.act == MK_ACT_RELU) epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds4k_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
                                              int lane, int g) {
@@ -811,8 +995,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   const T* W = (const T*)p.W + (long long)g * p.strideW_g;
   const int srow = lane >> 3, sp = lane & 7;
   // this wave's 4 A pieces (own half) and 4 W pieces of a stage; piece = 8 rows x 128 B
-  const T* wrow[4];
-  long long aoff[4];
+  // (32-bit element offsets: the launcher routes operands of 2^31 elements or more to the other kernels)
+  unsigned woff[4];
+  unsigned aoff[4];
   int ay[4], ax[4];
   bool avalid[4];
   auto set_w = [&](int n0) {
@@ -821,7 +1006,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       const int rw = (wave * 4 + j) * 8 + srow;
       int n = n0 + rw;
       n = n < p.N ? n : p.N - 1;
-      wrow[j] = W + (long long)n * p.ldw + swz8(rw, sp) * 8;
+      woff[j] = (unsigned)n * (unsigned)p.ldw + swz8(rw, sp) * 8;
     }
   };
   auto set_a = [&](int m0) {
@@ -832,7 +1017,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       avalid[j] = m < p.M;
       m = avalid[j] ? m : p.M - 1;
       if (AMODE == A_DENSE) {
-        aoff[j] = (long long)m * p.lda + swz8(ra, sp) * 8;
+        aoff[j] = (unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8;
       } else {
         const int pix = m % (p.H * p.Wd);
         ay[j] = pix / p.Wd;
@@ -847,7 +1032,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     char* sW = smem + ((pb + s) & 1) * STAGE_BYTES + A_BYTES;
     const int k0 = (s < nk ? s : s - nk) * BK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(wrow[j] + k0, sW + (wave * 4 + j) * 1024);
+    for (int j = 0; j < 4; ++j) glds16(W + (woff[j] + (unsigned)k0), sW + (wave * 4 + j) * 1024);
   };
   auto dma_a = [&](int s, int pb, bool more) {   // 4 instructions
     if (s >= nk && !more) return;
@@ -855,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     const int k0 = (s < nk ? s : s - nk) * BK;
     if (AMODE == A_DENSE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) glds16(A + aoff[j] + k0, sA + (wm * 16 + wn * 4 + j) * 1024);
+      for (int j = 0; j < 4; ++j) glds16(A + (aoff[j] + (unsigned)k0), sA + (wm * 16 + wn * 4 + j) * 1024);
     } else {
       const int kc = 9 * p.C1;
       const T* src;
@@ -878,7 +1063,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
         const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
         const int yy = ay[j] + dy, xx = ax[j] + dx;
         const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-        const T* sp_ = ok ? src + (aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
+        const T* sp_ = ok ? src + ((long long)aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
         glds16(sp_, sA + (wm * 16 + wn * 4 + j) * 1024);
       }
     }
@@ -912,6 +1097,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     __builtin_amdgcn_s_barrier();
   };
 
+  // next-tile addresses must be computed in the K-loop iteration that switches to them: hoisted in front of the loop
+  // (they are loop-invariant) they cost 8 more live VGPRs, which spills accumulators inside the loop
+  auto opaque = [](int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+  };
   int seq = blockIdx.x;
   int tm, tn;
   pp_tile_coords(xcd_remap(seq, ntiles), ntm, ntn, band_m, tm, tn);
@@ -944,8 +1135,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     }
     if (wm == 0) {
       for (int kt = 0; kt < nk; ++kt) {
-        if (more && kt == nk - 2) set_a(nm0);   // A DMAs from here on belong to the next tile
-        if (more && kt == nk - 1) set_w(nn0);
+        if (more && kt == nk - 2) set_a(opaque(nm0));   // A DMAs from here on belong to the next tile
+        if (more && kt == nk - 1) set_w(opaque(nn0));
         if (!(kt == 0 && skipbar)) bar();   // slot 4kt
         load_frags(wf, xf, (pb + kt) & 1, 0);
         dma_w(kt + 1, pb, more);
@@ -966,8 +1157,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       skipbar = true;
     } else {
       for (int kt = 0; kt < nk; ++kt) {
-        if (more && kt == nk - 2) set_a(nm0);
-        if (more && kt == nk - 1) set_w(nn0);
+        if (more && kt == nk - 2) set_a(opaque(nm0));
+        if (more && kt == nk - 1) set_w(opaque(nn0));
         bar();                      // slot 4kt+1
         load_frags(wf, xf, (pb + kt) & 1, 0);
         dma_w(kt + 1, pb, more);
@@ -982,9 +1173,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       }
     }
     if (DBG) t_loop = __builtin_amdgcn_s_memrealtime();
-    if (PERSIST)   // the ring already holds the next tile's first stages
-      epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
-    else
+    if (PERSIST) {   // the ring already holds the next tile's first stages: stage through the 32 KiB beside it
+      // opaque copy of the lane id: keeps the epilogue's per-lane address arithmetic from being hoisted out of the tile
+      // loop, where it would stay live across the K loop and spill (scratch traffic drains the counted DMA queue)
+      int elane = lane;
+      asm volatile("" : "+v"(elane));
+      epilogue_lds4k<T>(p, acc, smem + 2 * STAGE_BYTES + wave * 4096, m0, n0, wm, wn, elane, g);
+    } else
       epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g);
     if (DBG && wn == 0 && lane == 0) {
       unsigned long long* d = dbg + ((long long)seq * 2 + wm) * 6;
@@ -994,7 +1189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       d[3] = __builtin_amdgcn_s_memrealtime();
       d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
       d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-      t_entry = d[3];
+      t_entry = t_landed = d[3];
     }
     if (!more) break;
     seq = nseq;
@@ -1020,7 +1215,7 @@ int g_stagger_us = 0;                  // start-time spread of the first workgro
 
 template <typename T, int AMODE, bool PERSIST, bool DBG = false>
 int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
-  constexpr int LDS = 2 * 512 * 128;
+  constexpr int LDS = 2 * 512 * 128 + (PERSIST ? 8 * 4096 : 0);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1093,7 +1288,8 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
   if (g_force_tile == 1) big = false;
   if (g_force_tile == 2) big = true;
-  const bool k_ok = p.K >= 2 * BK;
+  const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
+                    (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
   const bool forced64 = g_force_tile == 5 || (g_force_tile >= 7 && g_force_tile <= 9);
   if (k_ok && (forced64 || ((g_force_tile == 0 || g_force_tile == 6) && big))) {
     // auto (0/6) and 7: one tile per workgroup, bands of 8 m-tiles (measured best: 6-16 % over the K=32 ring and the

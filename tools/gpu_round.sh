@@ -1,9 +1,5 @@
 #!/bin/bash
-timeout 1200 python -m pytest tests -q -x -m gpu 2>&1 | tail -3
-timeout 300 python tools/bench_epilogues.py 2>&1 | tail -2
-timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_a.json
-timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_b.json
-for f in a b; do python - <<PY
-import json; d=json.load(open("gpurun_out/bench_$f.json")); print("$f", round(d["value"],1), "pairs/s", round(d["roofline"]["achieved"],1), "TF", round(d["ms_per_step"],1), "ms")
-PY
-done
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm or conv3x3 or qkv or patch" 2>&1 | tail -2
+timeout 300 python tools/bench_gemm.py 7 5 2>&1 | tail -8
+timeout 300 python tools/bench_epilogues.py 2>&1 | tail -4
+timeout 300 python tools/gemm_timeline.py 5 2>&1 | tail -3
