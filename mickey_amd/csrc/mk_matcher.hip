@@ -44,136 +44,207 @@ __device__ __forceinline__ f32x16 corr_tile(const float* sA, const float* sB, in
   return acc;
 }
 
-__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {   // natural-log domain (Sinkhorn)
   const float M = fmaxf(m, m2);
   s = s * expf(m - M) + s2 * expf(m2 - M);
   m = M;
 }
 
-// pass 1.  grid (row_tiles, NCHUNK, B*2): side 0 -> rows of S, side 1 -> rows of S^T.
-// part[((b*2+side)*NCHUNK + chunk)*nmax + row][2] = (max, sum exp(S - max)) over the chunk's columns
-__global__ __launch_bounds__(256) void lse_partial_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
-                                                          float inv_t, float* __restrict__ part, int C, int n0, int n1,
-                                                          int nmax) {
-  __shared__ __attribute__((aligned(16))) float sA[CMAX * MT];
-  __shared__ __attribute__((aligned(16))) float sB[CMAX * MT];
-  float(*sred)[MT][2] = (float(*)[MT][2])sB;  // [2][MT][2], reuses sB after the last tile
-  const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+// ---- dual softmax: register-resident correlation ---------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 takes ONE float per lane per operand (lane l: row/column l & 31, k = 2 kk + (l >> 5)), so a
+// wave keeps the descriptors of its 32 rows in 64 VGPRs for its whole life and streams 32-column tiles of the other
+// image straight from L2 (descriptors are ~1 MB per image): 64 coalesced 4-byte loads + 64 MFMAs per tile, no LDS, no
+// barriers.  (The previous version staged 64 KiB through LDS with scalar loads per 64x64 tile and ran at ~10 % of the
+// fp32 matrix rate.)  Everything is kept in the log2 domain: v2 = S / T * log2(e), exp2 is one v_exp_f32.
+constexpr int RT = 32;       // rows per wave, columns per streamed tile
+constexpr int NCHUNK2 = 4;   // column chunks of pass 2
+
+__device__ __forceinline__ void lse2_merge(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  s = s * __builtin_amdgcn_exp2f(m - M) + s2 * __builtin_amdgcn_exp2f(m2 - M);
+  m = M;
+}
+
+// A-side operand: this lane's 64 k-values of row i0 + (lane & 31); rows >= n are zero
+template <bool FULLC>
+__device__ __forceinline__ void load_operand(float (&a)[CMAX / 2], const float* __restrict__ d, int C, int n, int i, int hi) {
+  const bool ok = i < n;
+  const float* pa = d + (long long)hi * n + (ok ? i : n - 1);
+#pragma unroll
+  for (int kk = 0; kk < CMAX / 2; ++kk) {
+    if (!FULLC && kk >= (C >> 1)) {
+      a[kk] = 0.f;
+    } else {
+      const float v = pa[(long long)kk * 2 * n];
+      a[kk] = ok ? v : 0.f;
+    }
+  }
+}
+
+// XCD-aware decode of a 1-D grid into (bx, by, unit): workgroups are dealt round-robin to the 8 XCDs, so the linear id
+// is re-read as (xcd, slot) and ALL gx*gy workgroups of a unit (an image pair [x side]) land on one XCD, whose 4-MiB L2
+// then holds that unit's ~2 MB of descriptors.  (Dealt naively, every XCD serves 8 pairs at a time, thrashes its L2 and
+// pulls 1.9 GB of 128-byte pieces from memory per pass: measured 1.9 ms instead of 0.4.)  The grid is padded to a
+// multiple of 8 units; returns false for padding.
+__device__ __forceinline__ bool decode_unit_grid(int gx, int gy, int nunits, int& bx, int& by, int& unit) {
+  const int L = blockIdx.x, per = gx * gy;
+  const int xcd = L & 7, slot = L >> 3;
+  unit = (slot / per) * 8 + xcd;
+  const int within = slot - (slot / per) * per;
+  bx = within % gx;
+  by = within / gx;
+  return unit < nunits;
+}
+
+// Scheduling directive for the tile body (one basic block): all 64 operand loads first, then the 64 MFMAs.  Left alone,
+// the scheduler keeps ONE operand register and emits load -> s_waitcnt vmcnt(0) -> MFMA, i.e. 64 serial memory round
+// trips per tile (measured 32 us per tile instead of ~3).
+#define MK_LOADS_THEN_MFMAS()                                  \
+  do {                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x020, CMAX / 2, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x002, CMAX / 2, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x008, CMAX / 2, 0);  \
+  } while (0)
+
+template <bool FULLC>
+__device__ __forceinline__ f32x16 corr_regs(const float (&a)[CMAX / 2], const float (&bq)[CMAX / 2], int C) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < CMAX / 2; ++kk) {
+    if (FULLC || kk < (C >> 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bq[kk], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// pass 1.  grid (row blocks of 128, NCHUNK, B*2), one wave per 32 rows: side 0 -> rows of S, side 1 -> rows of S^T.
+// part[((b*2+side)*NCHUNK + chunk)*nmax + row][2] = (max2, sum 2^(v2 - max2)) over the chunk's columns
+// amdgpu_waves_per_eu(2, 2): without it the scheduler chases occupancy, keeps ONE operand register and emits
+// load -> s_waitcnt vmcnt(0) -> MFMA 64 times per tile (64 serial memory round trips, measured 32 us per tile)
+template <bool FULLC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lse_partial_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
+                                                          float scale2, float* __restrict__ part, int C, int n0, int n1,
+                                                          int nmax, int gx, int nunits) {
+  int bx, by, unit;
+  if (!decode_unit_grid(gx, NCHUNK, nunits, bx, by, unit)) return;
+  const int b = unit >> 1, side = unit & 1;
   const int nA = side ? n1 : n0, nB = side ? n0 : n1;
   const float* dA = (side ? dsc1 + (long long)b * C * n1 : dsc0 + (long long)b * C * n0);
   const float* dB = (side ? dsc0 + (long long)b * C * n0 : dsc1 + (long long)b * C * n1);
-  const int i0 = blockIdx.x * MT;
-  if (i0 >= nA) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int ntB = (nB + MT - 1) / MT;
+  const int i0 = (bx * 4 + wave) * RT;
+  if (i0 >= nA) return;
+  float a[CMAX / 2], bq[CMAX / 2];
+  load_operand<FULLC>(a, dA, C, nA, i0 + l31, hi);
+  const int ntB = (nB + RT - 1) / RT;
   const int per = (ntB + NCHUNK - 1) / NCHUNK;
-  const int jt0 = blockIdx.y * per, jt1 = min(ntB, jt0 + per);
-
-  stage_desc(sA, dA, C, nA, i0);
-  float rm[16], rsum[16];
+  const int jt0 = by * per, jt1 = min(ntB, jt0 + per);
+  float rm[16], rs[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { rm[r] = -1e30f; rsum[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { rm[r] = -1e30f; rs[r] = 0.f; }
   for (int jt = jt0; jt < jt1; ++jt) {
-    __syncthreads();
-    stage_desc(sB, dB, C, nB, jt * MT);
-    __syncthreads();
-    const f32x16 acc = corr_tile(sA, sB, C, wi, wj, lane);
-    const bool colok = jt * MT + wj * 32 + l31 < nB;
-    if (colok) {
+    const int j = jt * RT + l31;
+    load_operand<FULLC>(bq, dB, C, nB, j, hi);
+    const f32x16 acc = corr_regs<FULLC>(a, bq, C);
+    MK_LOADS_THEN_MFMAS();
+    if (j < nB) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[r] * inv_t;
+        const float v = acc[r] * scale2;
         const float M = fmaxf(rm[r], v);
-        rsum[r] = rsum[r] * expf(rm[r] - M) + expf(v - M);
+        rs[r] = rs[r] * __builtin_amdgcn_exp2f(rm[r] - M) + __builtin_amdgcn_exp2f(v - M);
         rm[r] = M;
       }
     }
   }
-  // combine the 32 lanes that share rows (same hi), then the two column waves
+  // combine the 32 lanes that share rows (same hi)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
-      const float m2 = __shfl_xor(rm[r], o, 64), s2 = __shfl_xor(rsum[r], o, 64);
-      lse_merge(rm[r], rsum[r], m2, s2);
+      const float m2 = __shfl_xor(rm[r], o, 64), s2 = __shfl_xor(rs[r], o, 64);
+      lse2_merge(rm[r], rs[r], m2, s2);
     }
   }
-  __syncthreads();
   if (l31 == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      sred[wj][row][0] = rm[r];
-      sred[wj][row][1] = rsum[r];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < MT) {
-    const int row = threadIdx.x;
-    float m = sred[0][row][0], s = sred[0][row][1];
-    lse_merge(m, s, sred[1][row][0], sred[1][row][1]);
-    if (i0 + row < nA) {
-      float* o = part + ((((long long)b * 2 + side) * NCHUNK + blockIdx.y) * nmax + i0 + row) * 2;
-      o[0] = m;
-      o[1] = s;
+      const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row < nA) {
+        float* o = part + ((((long long)b * 2 + side) * NCHUNK + by) * nmax + row) * 2;
+        o[0] = rm[r];
+        o[1] = rs[r];
+      }
     }
   }
 }
 
-__device__ __forceinline__ float final_lse(const float* part, long long bs, int nmax, int row, int use_dustbin, float beta) {
+// merge the chunk partials (+ the dustbin term): lse2[(b*2+side)*nmax + row] = log2 sum 2^v2.  grid (nmax/256, 2, B)
+__global__ __launch_bounds__(256) void lse_final_kernel(const float* __restrict__ part, float* __restrict__ lse2, int use_dustbin,
+                                                        float beta2, int n0, int n1, int nmax) {
+  const int row = blockIdx.x * 256 + threadIdx.x, side = blockIdx.y, b = blockIdx.z;
+  if (row >= (side ? n1 : n0)) return;
+  const long long bs = (long long)b * 2 + side;
   float m = -1e30f, s = 0.f;
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) {
     const float* q = part + ((bs * NCHUNK + c) * nmax + row) * 2;
-    lse_merge(m, s, q[0], q[1]);
+    lse2_merge(m, s, q[0], q[1]);
   }
-  if (use_dustbin) lse_merge(m, s, beta, 1.0f);
-  return m + logf(s);
+  if (use_dustbin) lse2_merge(m, s, beta2, 1.0f);
+  lse2[bs * nmax + row] = m + __builtin_amdgcn_logf(s);   // v_log_f32 is log2
 }
 
-// pass 2.  grid (col_tiles, row_tiles, B)
-__global__ __launch_bounds__(256) void dual_softmax_write_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
+// pass 2.  grid (row blocks of 128, NCHUNK2, B), one wave per 32 rows: recompute the tile, write
+// scores = softmax_rows * softmax_cols = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores * kp
+template <bool FULLC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_write_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
                                                                  const float* __restrict__ scr0, const float* __restrict__ scr1,
-                                                                 float inv_t, int use_dustbin, float beta,
-                                                                 const float* __restrict__ part, float* __restrict__ scores,
-                                                                 float* __restrict__ kp, float* __restrict__ fin, int C, int n0,
-                                                                 int n1, int nmax) {
-  __shared__ __attribute__((aligned(16))) float sA[CMAX * MT];
-  __shared__ __attribute__((aligned(16))) float sB[CMAX * MT];
-  float *slr = sA, *slc = sA + MT, *ss0 = sA + 2 * MT, *ss1 = sA + 3 * MT;  // reuse sA after the MFMAs
-  const int b = blockIdx.z, i0 = blockIdx.y * MT, j0 = blockIdx.x * MT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1;
+                                                                 float scale2, const float* __restrict__ lse2,
+                                                                 float* __restrict__ scores, float* __restrict__ kp,
+                                                                 float* __restrict__ fin, int C, int n0, int n1, int nmax,
+                                                                 int gx, int nunits) {
+  int bx, by, b;
+  if (!decode_unit_grid(gx, NCHUNK2, nunits, bx, by, b)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  stage_desc(sA, dsc0 + (long long)b * C * n0, C, n0, i0);
-  stage_desc(sB, dsc1 + (long long)b * C * n1, C, n1, j0);
-  __syncthreads();
-  const f32x16 acc = corr_tile(sA, sB, C, wi, wj, lane);
-  __syncthreads();
-  if (threadIdx.x < MT) {
-    const int i = i0 + threadIdx.x;
-    slr[threadIdx.x] = i < n0 ? final_lse(part, (long long)b * 2 + 0, nmax, i, use_dustbin, beta) : 0.f;
-    ss0[threadIdx.x] = (scr0 && i < n0) ? scr0[(long long)b * n0 + i] : 0.f;
-  } else if (threadIdx.x < 2 * MT) {
-    const int t = threadIdx.x - MT, jx = j0 + t;
-    slc[t] = jx < n1 ? final_lse(part, (long long)b * 2 + 1, nmax, jx, use_dustbin, beta) : 0.f;
-    ss1[t] = (scr1 && jx < n1) ? scr1[(long long)b * n1 + jx] : 0.f;
-  }
-  __syncthreads();
-  const int jl = wj * 32 + l31, jx = j0 + jl;
-  if (jx >= n1) return;
-  const float lc = slc[jl], s1 = ss1[jl];
+  const int i0 = (bx * 4 + wave) * RT;
+  if (i0 >= n0) return;
+  float a[CMAX / 2], bq[CMAX / 2];
+  load_operand<FULLC>(a, dsc0 + (long long)b * C * n0, C, n0, i0 + l31, hi);
+  float lr[16], s0[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int il = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, i = i0 + il;
-    if (i >= n0) continue;
-    const float v = acc[r] * inv_t;
-    const float pr = expf(v - lc) * expf(v - slr[il]);  // softmax over dim 1 (column-normalised) * dim 2
-    const long long o = ((long long)b * n0 + i) * n1 + jx;
-    const float kk = ss0[il] * s1;
-    if (scores) scores[o] = pr;
-    if (kp) kp[o] = kk;
-    if (fin) fin[o] = pr * kk;
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    lr[r] = i < n0 ? lse2[((long long)b * 2 + 0) * nmax + i] : 0.f;
+    s0[r] = (scr0 && i < n0) ? scr0[(long long)b * n0 + i] : 0.f;
+  }
+  const float* dB = dsc1 + (long long)b * C * n1;
+  const int ntB = (n1 + RT - 1) / RT;
+  const int per = (ntB + NCHUNK2 - 1) / NCHUNK2;
+  const int jt0 = by * per, jt1 = min(ntB, jt0 + per);
+  for (int jt = jt0; jt < jt1; ++jt) {
+    const int j = jt * RT + l31;
+    load_operand<FULLC>(bq, dB, C, n1, j, hi);
+    const f32x16 acc = corr_regs<FULLC>(a, bq, C);
+    MK_LOADS_THEN_MFMAS();
+    if (j >= n1) continue;
+    const float lc = lse2[((long long)b * 2 + 1) * nmax + j];
+    const float s1 = scr1 ? scr1[(long long)b * n1 + j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (i >= n0) continue;
+      const float v = acc[r] * scale2;
+      const float pr = __builtin_amdgcn_exp2f((v - lc) + (v - lr[r]));  // softmax over dim 1 times softmax over dim 2
+      const long long o = ((long long)b * n0 + i) * n1 + j;
+      const float kk = s0[r] * s1;
+      if (scores) scores[o] = pr;
+      if (kp) kp[o] = kk;
+      if (fin) fin[o] = pr * kk;
+    }
   }
 }
 
@@ -385,7 +456,7 @@ extern "C" {
 
 long long mk_dual_softmax_work_floats(int B, int n0, int n1) {
   const int nmax = n0 > n1 ? n0 : n1;
-  return (long long)B * 2 * NCHUNK * nmax * 2;
+  return (long long)B * 2 * NCHUNK * nmax * 2 + (long long)B * 2 * nmax;   // chunk partials + final log2-sum-exp vectors
 }
 
 int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
@@ -396,12 +467,26 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
   MK_CHECK_ARG((scr0 && scr1) || (!kp_scores && !final_scores), "mk_dual_softmax: kp/final scores need scr0 and scr1");
   hipStream_t st = (hipStream_t)stream;
   const int nmax = n0 > n1 ? n0 : n1;
-  const int rt = (nmax + MT - 1) / MT;
-  hipLaunchKernelGGL(lse_partial_kernel, dim3(rt, NCHUNK, B * 2), dim3(256), 0, st, dsc0, dsc1, inv_temperature, work, C, n0, n1,
-                     nmax);
+  const float LOG2E = 1.4426950408889634f;
+  const float scale2 = inv_temperature * LOG2E;
+  float* part = work;
+  float* lse2 = work + (long long)B * 2 * NCHUNK * nmax * 2;
+  const int gx1 = (nmax + 4 * RT - 1) / (4 * RT), gx2 = (n0 + 4 * RT - 1) / (4 * RT);
+  const dim3 g1((unsigned)gx1 * NCHUNK * ((B * 2 + 7) / 8 * 8)), g2((unsigned)gx2 * NCHUNK2 * ((B + 7) / 8 * 8));   // see decode_unit_grid
+  if (C == CMAX)
+    hipLaunchKernelGGL(lse_partial_kernel<true>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, part, C, n0, n1, nmax, gx1, B * 2);
+  else
+    hipLaunchKernelGGL(lse_partial_kernel<false>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, part, C, n0, n1, nmax, gx1, B * 2);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dual_softmax_write_kernel, dim3((n1 + MT - 1) / MT, (n0 + MT - 1) / MT, B), dim3(256), 0, st, dsc0, dsc1,
-                     scr0, scr1, inv_temperature, use_dustbin, dustbin, work, scores, kp_scores, final_scores, C, n0, n1, nmax);
+  hipLaunchKernelGGL(lse_final_kernel, dim3((nmax + 255) / 256, 2, B), dim3(256), 0, st, part, lse2, use_dustbin, dustbin * LOG2E, n0,
+                     n1, nmax);
+  MK_CHECK_LAUNCH();
+  if (C == CMAX)
+    hipLaunchKernelGGL(dual_softmax_write_kernel<true>, g2, dim3(256), 0, st, dsc0, dsc1, scr0, scr1, scale2, lse2, scores,
+                       kp_scores, final_scores, C, n0, n1, nmax, gx2, B);
+  else
+    hipLaunchKernelGGL(dual_softmax_write_kernel<false>, g2, dim3(256), 0, st, dsc0, dsc1, scr0, scr1, scale2, lse2, scores,
+                       kp_scores, final_scores, C, n0, n1, nmax, gx2, B);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
