@@ -14,6 +14,8 @@
 //    to 16 bit) -- no cross-lane movement -- because mk_gemm_qkv stores V^T with token bits 2<->3
 //    swapped, which makes the 8 keys a lane owns per k-step one contiguous 16-byte LDS chunk.
 //  * q arrives pre-multiplied by 64^-0.5*log2(e); softmax uses exp2.
+#include <type_traits>
+
 #include "mk_common.hpp"
 
 namespace {
@@ -75,10 +77,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 
   const int nkt = (ntok + 63) >> 6;
   stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One KV tile.  LAST is a compile-time tag: only the peeled final tile carries the key mask -- written as a runtime
+  // condition inside one loop it was if-converted into 32 v_cmp + 32 v_cndmask per query block on EVERY tile (~12 % of
+  // the VALU work of a loop that is VALU-bound).
+  auto kv_tile = [&](const int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    if (!LAST) stage((kt + 1) & 1, kt + 1);
     const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
 
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     V8 pf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      if (kt == nkt - 1 && (ntok & 63)) {
+      if (LAST && (ntok & 63)) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -157,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
         for (int qb = 0; qb < QB; ++qb) o[qb][dt] = Lp<T>::mma32(vf, pf[qb][s4], o[qb][dt]);
       }
     }
-  }
+  };
+  for (int kt = 0; kt < nkt - 1; ++kt) kv_tile(kt, std::false_type{});
+  kv_tile(nkt - 1, std::true_type{});
 
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {

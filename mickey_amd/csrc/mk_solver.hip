@@ -4,9 +4,10 @@
 // The reference materialises a [20B, n*n] tiled copy of final_scores (300 MB / pair), a same-sized
 // Exp(1) noise tensor and a full top-k for its outer torch.multinomial, then tiles X/Y 100x for the
 // inner one.  Here:
-//   * mk_exprace_topk: ONE streamed read of final_scores per group of 4 rows, Philox noise generated
-//     in registers, radix-histogram threshold + small in-LDS bitonic sort -> the same "top-k of
-//     p / Exp(1)" selection, in the same (descending key) order torch.topk returns.
+//   * mk_exprace_topk: a threshold from the histogram of p alone (expected tail count of the race keys), ONE
+//     streamed read of final_scores per group of 4 rows with Philox noise generated in registers, small in-LDS
+//     bitonic sort -> the same "top-k of p / Exp(1)" selection, in the same (descending key) order torch.topk
+//     returns; an exact radix-histogram path takes over on device if a row collected too few / too many.
 //   * mk_ransac_hypotheses: a correspondence set (X, Y, w: 56 KB) is staged once in LDS and shared by
 //     all its hypotheses; one wave per hypothesis: exponential-race 3-sample (wave arg-max), 3x3
 //     Kabsch via one-sided Jacobi SVD in fp64 (warp-serial, no MFMA), soft inlier count by wave64
@@ -53,9 +54,11 @@ constexpr int CAND_MAX = 8192;  // candidates kept per row (expected ~k * 1.1)
 constexpr int CELL_BLOCKS = 128;
 
 struct TopkWork {
-  unsigned* hist;            // [R][NBINS]
+  unsigned* hist;            // [R][NBINS]   key histogram of the exact (fallback) path
   int* thr;                  // [R]
   unsigned* ncand;           // [R]
+  unsigned* phist;           // [B][NBINS]   histogram of p itself (analytic threshold)
+  int* redo;                 // [1] set when a row collected fewer than k candidates above an analytic threshold
   unsigned long long* cand;  // [R][CAND_MAX]
   int* invalid;              // [1] or null
 };
@@ -78,29 +81,38 @@ __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsign
   }
 }
 
-template <int PASS>  // 0: histogram, 1: collect
+// Collect pass: candidates are appended to a per-block LDS buffer (LDS atomics return in ~100 cycles) and flushed with ONE
+// global atomic per row per block at the end.  Appending straight to global memory stalls the whole wave for a memory
+// round trip whenever any of its 256 keys is a candidate -- inside the Philox loop that was ~25 % of the pass.
+constexpr int LCAP = 960;   // LDS candidate slots per row and block (expected ~25 at k = 2048, 128 blocks); overflow goes direct
+
+template <int PASS, bool REDO = false>  // 0: histogram, 1: collect; REDO: part of the exact fallback, runs only if w.redo is set
 __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restrict__ p, const float* __restrict__ noise,
                                                            unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
                                                            TopkWork w, int rows_per_pair, long long ncell) {
-  __shared__ unsigned sh[RG * NBINS];
+  __shared__ unsigned sh[RG * NBINS];   // pass 0: key histograms; pass 1: [RG][LCAP] candidates (2 words each) + counters
+  __shared__ unsigned lcount[RG], lbase[RG];
+  if (REDO && *w.redo == 0) return;
   const int b = blockIdx.z, grp = blockIdx.y;
   const long long per = (ncell + gridDim.x - 1) / gridDim.x;
   const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
+  unsigned long long* lbuf = (unsigned long long*)sh;   // [RG][LCAP]
+  static_assert(RG * LCAP * 8 <= RG * NBINS * 4, "candidate buffer must fit the histogram array");
   int thr[RG];
   if (PASS == 0) {
     for (int i = threadIdx.x; i < RG * NBINS; i += 256) sh[i] = 0;
-    __syncthreads();
   } else {
+    if (threadIdx.x < RG) lcount[threadIdx.x] = 0;
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int r = grp * RG + q;
       thr[q] = r < rows_per_pair ? w.thr[b * rows_per_pair + r] : NBINS;
     }
   }
+  __syncthreads();
   const float* pb = p + (long long)b * ncell;
   for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
     const float pv = pb[c];
-    if (PASS == 0 && w.invalid && grp == 0 && (!(pv >= 0.f) || isinf(pv))) atomicOr(w.invalid, 1);
     if (!(pv > 0.f) || isinf(pv)) continue;
     float key[RG];
     row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key);
@@ -113,18 +125,39 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
       if (PASS == 0) {
         atomicAdd(&sh[q * NBINS + bin], 1u);
       } else if (bin >= thr[q]) {
-        const int row = b * rows_per_pair + r;
-        const unsigned slot = atomicAdd(&w.ncand[row], 1u);
-        if (slot < CAND_MAX)
-          w.cand[(long long)row * CAND_MAX + slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+        const unsigned long long item = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+        const unsigned ls = atomicAdd(&lcount[q], 1u);
+        if (ls < (unsigned)LCAP) {
+          lbuf[q * LCAP + ls] = item;
+        } else {   // block-local overflow (pathological inputs): append directly
+          const int row = b * rows_per_pair + r;
+          const unsigned slot = atomicAdd(&w.ncand[row], 1u);
+          if (slot < CAND_MAX) w.cand[(long long)row * CAND_MAX + slot] = item;
+        }
       }
     }
   }
+  __syncthreads();
   if (PASS == 0) {
-    __syncthreads();
     for (int i = threadIdx.x; i < RG * NBINS; i += 256) {
       const int q = i / NBINS, r = grp * RG + q;
       if (sh[i] && r < rows_per_pair) atomicAdd(&w.hist[((long long)b * rows_per_pair + r) * NBINS + (i % NBINS)], sh[i]);
+    }
+  } else {
+    if (threadIdx.x < RG) {
+      const int q = threadIdx.x, r = grp * RG + q;
+      const unsigned nloc = min(lcount[q], (unsigned)LCAP);
+      lbase[q] = (r < rows_per_pair && nloc) ? atomicAdd(&w.ncand[b * rows_per_pair + r], nloc) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int r = grp * RG + q;
+      if (r >= rows_per_pair) continue;
+      const unsigned nloc = min(lcount[q], (unsigned)LCAP), base = lbase[q];
+      const long long row = (long long)b * rows_per_pair + r;
+      for (unsigned i = threadIdx.x; i < nloc; i += 256)
+        if (base + i < (unsigned)CAND_MAX) w.cand[row * CAND_MAX + base + i] = lbuf[q * LCAP + i];
     }
   }
 }
@@ -132,6 +165,7 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
 // one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
 __global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k) {
   __shared__ unsigned part[256];
+  if (*w.redo == 0) return;   // exact fallback only
   const int row = blockIdx.x, t = threadIdx.x;
   const unsigned* h = w.hist + (long long)row * NBINS;
   // thread t owns bins [t*8, t*8+8); suffix sums from the top
@@ -155,6 +189,84 @@ __global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int 
     }
     w.thr[row] = tb;
   }
+}
+
+// ---- analytic threshold --------------------------------------------------------------------------------------
+// The number of race keys p_i / E_i (E_i ~ Exp(1)) above T is a sum of independent Bernoulli(1 - exp(-p_i / T)): its
+// mean is a function of p alone, shared by all draws of a pair.  So instead of generating all rows_per_pair x ncell
+// keys once just to histogram them (a full Philox pass), histogram p (one RNG-free read), pick the key bin whose
+// expected tail count is >= 1.25 k (k = 2048: +11 sigma) and go straight to the collect pass.  The result is still
+// the EXACT top-k of the keys as long as a row collected >= k candidates; otherwise `redo` is raised and the exact
+// histogram passes below run (they early-exit on the flag, so the common case pays only their launch).
+__global__ __launch_bounds__(256) void exprace_phist_kernel(const float* __restrict__ p, TopkWork w, long long ncell) {
+  __shared__ unsigned sh[NBINS];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < NBINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  const long long per = (ncell + gridDim.x - 1) / gridDim.x;
+  const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
+  const float* pb = p + (long long)b * ncell;
+  bool bad = false;
+  for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
+    const float pv = pb[c];
+    bad |= !(pv >= 0.f) || isinf(pv);
+    if (pv > 0.f && !isinf(pv)) atomicAdd(&sh[__float_as_uint(pv) >> 20], 1u);
+  }
+  if (bad && w.invalid) atomicOr(w.invalid, 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NBINS; i += 256)
+    if (sh[i]) atomicAdd(&w.phist[(long long)b * NBINS + i], sh[i]);
+}
+
+// one block per pair: largest key bin t whose expected tail count sum_bins h[pb] * (1 - exp(-p_mid(pb) / T_t)) >= need
+__global__ __launch_bounds__(256) void exprace_athresh_kernel(TopkWork w, int rows_per_pair, float need) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float hp[8], pm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int bin = t * 8 + i;
+    hp[i] = (float)w.phist[(long long)b * NBINS + bin];
+    pm[i] = __uint_as_float(((unsigned)bin << 20) | (1u << 19));   // middle of the bin
+  }
+  auto expected = [&](int tb) {   // block-wide; every thread returns the total
+    const float T = __uint_as_float((unsigned)tb << 20);           // lower edge of key bin tb
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (hp[i] > 0.f) a += hp[i] * -expm1f(-pm[i] / T);
+    red[t] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) red[t] += red[t + o];
+      __syncthreads();
+    }
+    const float tot = red[0];
+    __syncthreads();
+    return tot;
+  };
+  // bins >= 0x7f8 are inf / nan; bin 0 means "collect every positive key"
+  int lo = 0, hi = 0x7f7;
+  if (expected(1) >= need) {
+    lo = 1;
+    while (lo < hi) {   // invariant: expected(lo) >= need
+      const int mid = (lo + hi + 1) >> 1;
+      if (expected(mid) >= need) lo = mid; else hi = mid - 1;
+    }
+  }
+  for (int r = t; r < rows_per_pair; r += 256) w.thr[b * rows_per_pair + r] = lo;
+}
+
+// raise `redo` if a row fell short of k candidates although its threshold was not "everything", or overflowed its
+// candidate buffer (noise that is not Exp(1)-distributed can do either)
+__global__ void exprace_check_kernel(TopkWork w, int R, int k) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < R && ((w.thr[row] > 0 && w.ncand[row] < (unsigned)k) || w.ncand[row] > (unsigned)CAND_MAX)) atomicOr(w.redo, 1);
+}
+__global__ void exprace_rezero_kernel(TopkWork w, int R) {   // before the exact collect pass of the fallback
+  if (*w.redo == 0) return;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < R) w.ncand[row] = 0;
 }
 
 // one block per row: sort the candidates (key desc, index asc), emit the top k
@@ -569,12 +681,14 @@ __global__ void finalize_kernel(float* R, float* t, float* conf, const int* inva
   if (i < B) conf[i] = 0.f;
 }
 
-TopkWork carve(void* work, int R) {
+TopkWork carve(void* work, int R, int B) {
   TopkWork w;
   char* p = (char*)work;
   w.hist = (unsigned*)p;  p += (size_t)R * NBINS * 4;
   w.thr = (int*)p;        p += (size_t)R * 4;
   w.ncand = (unsigned*)p; p += (size_t)R * 4;
+  w.phist = (unsigned*)p; p += (size_t)B * NBINS * 4;
+  w.redo = (int*)p;       p += 4;
   p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   w.cand = (unsigned long long*)p;
   return w;
@@ -587,7 +701,7 @@ extern "C" {
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k) {
   (void)k;
   const long long R = (long long)B * rows_per_pair;
-  return R * NBINS * 4 + R * 8 + 16 + R * CAND_MAX * 8;
+  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4 + 16 + R * CAND_MAX * 8;
 }
 
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx, int* cnt,
@@ -599,21 +713,29 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   MK_CHECK_ARG(((uintptr_t)work & 15) == 0, "mk_exprace_topk: work must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int R = B * rows_per_pair;
-  TopkWork w = carve(work, R);
+  TopkWork w = carve(work, R, B);
   w.invalid = invalid;
-  const long long nz = (long long)R * NBINS + 2LL * R;
-  hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand are contiguous
+  const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + 1;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand | phist | redo are contiguous
   MK_CHECK_LAUNCH();
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), ol = (unsigned)offset, oh = (unsigned)(offset >> 32);
   const int groups = (rows_per_pair + RG - 1) / RG;
   int cb = CELL_BLOCKS;
   if ((long long)cb * 256 > ncell) cb = (int)((ncell + 255) / 256);
   dim3 grid(cb, groups, B);
-  hipLaunchKernelGGL(exprace_scan_kernel<0>, grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  // analytic threshold from the histogram of p, then ONE noise pass (collect)
+  hipLaunchKernelGGL(exprace_phist_kernel, dim3(cb, B), dim3(256), 0, st, p, w, ncell);
   MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(exprace_athresh_kernel, dim3(B), dim3(256), 0, st, w, rows_per_pair, 1.25f * (float)k);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  MK_CHECK_LAUNCH();
+  // exact fallback (runs only if a row came up short: never observed, kept for adversarial inputs / injected noise)
+  hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k);
+  hipLaunchKernelGGL((exprace_scan_kernel<0, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
   hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k);
-  MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(exprace_scan_kernel<1>, grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  hipLaunchKernelGGL(exprace_rezero_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R);
+  hipLaunchKernelGGL((exprace_scan_kernel<1, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(1024), (size_t)CAND_MAX * 8, st, p, w, idx, cnt, rows_per_pair, ncell,
                      k);

@@ -75,6 +75,25 @@ def test_sampler_full_size_bit_exact():
     _assert_same_sample(idx, ref, keys)
 
 
+@pytest.mark.parametrize("scale", [30.0, 1.0 / 200.0])
+def test_sampler_exact_fallback(scale):
+    """Noise that is NOT Exp(1)-distributed defeats the analytic threshold (too few / too many candidates above it): the
+    on-device exact histogram path must take over and still return torch.topk(p / noise)."""
+    from mickey_amd import ops
+    dev = _dev()
+    data, _, _ = _problem(B=2)
+    fs = data["final_scores"]
+    B, n, _ = fs.shape
+    rows = 4
+    g = torch.Generator().manual_seed(11)
+    noise = torch.empty((B * rows, n * n)).exponential_(1.0, generator=g) * scale
+    keys = fs.reshape(B, 1, n * n).expand(B, rows, n * n).reshape(B * rows, n * n) / noise
+    ref = torch.topk(keys, 2048).indices
+    idx, cnt = ops.exprace_topk(fs.reshape(B, n * n).to(dev), rows, 2048, noise=noise.to(dev))
+    assert (cnt.cpu() == 2048).all()
+    _assert_same_sample(idx, ref, keys)
+
+
 def test_sampler_philox_properties():
     from mickey_amd import ops
     dev = _dev()
