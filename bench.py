@@ -170,7 +170,7 @@ def main():
         g = prof.summary()
         roof = None
         if g:
-            roof = {"bound": "mfma", "kernel": "gemm_kernel<%s> (encoder linears: qkv, proj, fc1, fc2)" % args.dtype,
+            roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2)" % args.dtype,
                     "achieved": g["tflops"], "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": g["tflops"] / PEAK_MFMA_TF,
                     "traffic": pmc_traffic_bytes(B), "traffic_unit": "bytes/launch (L2-miss side, PMC)",
                     "algorithmic_bytes_per_launch": 1.403e9 * B / 32.0, "launches": g["launches"], "avg_launch_ms": g["avg_launch_ms"],

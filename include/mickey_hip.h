@@ -104,12 +104,14 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
 /* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
  * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
  * out lp [nimg*ntok, ldo] with column head*64 + d. */
-/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave, 2 = 64 queries/wave, 3 = software-pipelined
- * (QK^T of tile t+1 overlaps the softmax of tile t), 4 = VALU-lean (max folded into the MFMA accumulator init, row sums
- * on the matrix pipe), 5 = VALU-lean with 8 waves.  Process-wide; for benchmarks and tests. */
-int mk_attn_set_mode(int mode);
 int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads, int ntok,
                       int ntok_pad, int dtype, mk_stream_t stream);
+
+/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave,
+ * 2 = 64 queries/wave, 3 = software-pipelined (QK^T of tile t+1 overlaps the softmax of tile t), 4 = VALU-lean (max
+ * folded into the MFMA accumulator init, row sums on the matrix pipe), 5 = VALU-lean with 8 waves.  Process-wide; for
+ * benchmarks and tests. */
+int mk_attn_set_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Heads (reference lib/models/MicKey/modules/mickey_extractor.py:67-251)

@@ -88,6 +88,13 @@ __device__ __forceinline__ void load_operand(float (&a)[CMAX / 2], const float* 
 // multiple of 8 units; returns false for padding.
 __device__ __forceinline__ bool decode_unit_grid(int gx, int gy, int nunits, int& bx, int& by, int& unit) {
   const int L = blockIdx.x, per = gx * gy;
+  if (nunits < 8) {   // too few units to give every XCD one: spread each unit over the whole chip instead
+    unit = L / per;
+    const int within = L - unit * per;
+    bx = within % gx;
+    by = within / gx;
+    return unit < nunits;
+  }
   const int xcd = L & 7, slot = L >> 3;
   unit = (slot / per) * 8 + xcd;
   const int within = slot - (slot / per) * per;

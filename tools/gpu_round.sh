@@ -1,7 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_solver_gpu.py -q -x 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_model_gpu.py -q -x 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof -o b32 -- python /root/repo/bench.py --no-cpu-baseline --no-kernel-events --steps 3 --warmup 1 > /root/repo/gpurun_out/prof_bench.log 2>&1
-tail -1 /root/repo/gpurun_out/prof_bench.log | cut -c1-100
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof1 -o b1 -- python /root/repo/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events > /root/repo/gpurun_out/prof_b1.log 2>&1
+tail -1 /root/repo/gpurun_out/prof_b1.log | cut -c1-200

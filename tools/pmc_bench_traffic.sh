@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if r["Counter_Name"] != c: continue
-        if "gemm_kernel" in k and "Li0ELi8ELi2ELi4" in k: acc["gemm_dense_256"].append(float(r["Counter_Value"]))
+        if "gemm_pp64_kernel" in k and "Li0ELb0" in k: acc["gemm_dense_256"].append(float(r["Counter_Value"]))
         elif "attn_fwd" in k: acc["attn"].append(float(r["Counter_Value"]))
         elif "layernorm" in k: acc["layernorm"].append(float(r["Counter_Value"]))
     out[c] = {k: {"launches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in acc.items()}
