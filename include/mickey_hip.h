@@ -204,8 +204,14 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  *          the zero pose for the whole batch (probabilisticProcrustes.py:331-336)
  *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k), 16-byte aligned */
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k);
-int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx,
-                    int* cnt, int* invalid, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream);
+int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
+                    const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
+                    long long ncell, int k, mk_stream_t stream);
+
+/* *counter += inc on the stream.  `offset_dev` of mk_exprace_topk / mk_ransac_hypotheses (may be NULL) is such a
+ * counter: the Philox stream offset used is offset + *offset_dev, read on the device when the kernel runs, so a
+ * captured hipGraph of the forward draws fresh samples at every replay (the reference advances torch's generator). */
+int mk_counter_add(unsigned long long* counter, unsigned long long inc, mk_stream_t stream);
 
 /* Index decode + gathers + back-projection (probabilisticProcrustes.py:233-244, training_utils.py:7-22):
  * for every sampled cell c = idx[r, s]: i = c / n1 (image-0 keypoint), j = c % n1;
@@ -223,8 +229,9 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
  * 3 point pairs, score = sum_j sigmoid(5/th * (th - sqrt(|R X_j + t - Y_j|^2 + 1e-6))).
  *   Rh [R*it_ransac, 9], th [R*it_ransac, 3], score [R*it_ransac], idx3 int32 [R*it_ransac, 3] (out) */
 int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
-                         unsigned long long seed, unsigned long long offset, float th_soft, float* Rh, float* th,
-                         float* score, int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream);
+                         unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev,
+                         float th_soft, float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k,
+                         mk_stream_t stream);
 
 /* Arg-max over a pair's hypotheses, <= num_ref rounds of {hard-inlier recount, masked weighted Kabsch},
  * final confidence (probabilisticProcrustes.py:275-303, loss/solvers.py:13-26, training_utils.py:71-75).

@@ -44,9 +44,10 @@ SIGNATURES = {
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iii"),
-    "mk_exprace_topk": ("i", "ppuuppppiilip"),
+    "mk_exprace_topk": ("i", "ppuupppppiilip"),
+    "mk_counter_add": ("i", "pup"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),
-    "mk_ransac_hypotheses": ("i", "pppppuufppppiiip"),
+    "mk_ransac_hypotheses": ("i", "pppppuupfppppiiip"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),
     "mk_pose_finalize": ("i", "ppppip"),
 }

@@ -47,6 +47,16 @@ __device__ __forceinline__ float race_key(float p, unsigned r) {
   return p * __builtin_amdgcn_rcpf(e);
 }
 
+// Optional device-resident part of the Philox stream offset (a captured hipGraph re-reads it at every replay)
+__device__ __forceinline__ void add_device_offset(unsigned& off_lo, unsigned& off_hi, const unsigned long long* offp) {
+  if (!offp) return;
+  const unsigned long long o = (((unsigned long long)off_hi << 32) | off_lo) + *offp;
+  off_lo = (unsigned)o;
+  off_hi = (unsigned)(o >> 32);
+}
+
+__global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long inc) { *ctr += inc; }
+
 // ---- exponential-race top-k -------------------------------------------------------------------------
 constexpr int NBINS = 2048;     // bits 30..20 of a positive float: exponent + 3 mantissa bits
 constexpr int RG = 4;           // rows per group = draws per Philox call
@@ -89,10 +99,12 @@ constexpr int LCAP = 960;   // LDS candidate slots per row and block (expected ~
 template <int PASS, bool REDO = false>  // 0: histogram, 1: collect; REDO: part of the exact fallback, runs only if w.redo is set
 __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restrict__ p, const float* __restrict__ noise,
                                                            unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
-                                                           TopkWork w, int rows_per_pair, long long ncell) {
+                                                           const unsigned long long* __restrict__ offp, TopkWork w,
+                                                           int rows_per_pair, long long ncell) {
   __shared__ unsigned sh[RG * NBINS];   // pass 0: key histograms; pass 1: [RG][LCAP] candidates (2 words each) + counters
   __shared__ unsigned lcount[RG], lbase[RG];
   if (REDO && *w.redo == 0) return;
+  add_device_offset(off_lo, off_hi, offp);
   const int b = blockIdx.z, grp = blockIdx.y;
   const long long per = (ncell + gridDim.x - 1) / gridDim.x;
   const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
@@ -449,10 +461,13 @@ __device__ __forceinline__ float pt_dist(const float* R, const float* t, const f
 __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                          const float* __restrict__ wts, const float* __restrict__ noise3,
                                                          const int* __restrict__ idx3_in, unsigned k0, unsigned k1,
-                                                         unsigned off_lo, unsigned off_hi, float th_soft, float* __restrict__ Rh,
-                                                         float* __restrict__ th, float* __restrict__ score,
-                                                         int* __restrict__ idx3, int it_ransac, int k, int nsplit) {
+                                                         unsigned off_lo, unsigned off_hi,
+                                                         const unsigned long long* __restrict__ offp, float th_soft,
+                                                         float* __restrict__ Rh, float* __restrict__ th,
+                                                         float* __restrict__ score, int* __restrict__ idx3, int it_ransac, int k,
+                                                         int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // X[k*3] | Y[k*3] | w[k]
+  add_device_offset(off_lo, off_hi, offp);
   float* sX = lds;
   float* sY = lds + (size_t)k * 3;
   float* sW = lds + (size_t)k * 6;
@@ -704,8 +719,16 @@ long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k) {
   return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4 + 16 + R * CAND_MAX * 8;
 }
 
-int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset, int* idx, int* cnt,
-                    int* invalid, void* work, int B, int rows_per_pair, long long ncell, int k, mk_stream_t stream) {
+int mk_counter_add(unsigned long long* counter, unsigned long long inc, mk_stream_t stream) {
+  MK_CHECK_ARG(counter, "mk_counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
+                    const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
+                    long long ncell, int k, mk_stream_t stream) {
   MK_CHECK_ARG(p && idx && cnt && work, "mk_exprace_topk: null pointer");
   MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && rows_per_pair <= 64 * RG && ncell > 0 && ncell < (1LL << 31) && k > 0 &&
                    k <= CAND_MAX / 2,
@@ -728,14 +751,14 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(exprace_athresh_kernel, dim3(B), dim3(256), 0, st, w, rows_per_pair, 1.25f * (float)k);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
   MK_CHECK_LAUNCH();
   // exact fallback (runs only if a row came up short: never observed, kept for adversarial inputs / injected noise)
   hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k);
-  hipLaunchKernelGGL((exprace_scan_kernel<0, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  hipLaunchKernelGGL((exprace_scan_kernel<0, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
   hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k);
   hipLaunchKernelGGL(exprace_rezero_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R);
-  hipLaunchKernelGGL((exprace_scan_kernel<1, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, w, rows_per_pair, ncell);
+  hipLaunchKernelGGL((exprace_scan_kernel<1, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(1024), (size_t)CAND_MAX * 8, st, p, w, idx, cnt, rows_per_pair, ncell,
                      k);
@@ -756,8 +779,8 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
 }
 
 int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
-                         unsigned long long seed, unsigned long long offset, float th_soft, float* Rh, float* th, float* score,
-                         int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream) {
+                         unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev, float th_soft,
+                         float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream) {
   MK_CHECK_ARG(X && Y && wts && Rh && th && score && idx3, "mk_ransac_hypotheses: null pointer");
   MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 28 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 5485)");
   const int nsplit = it_ransac >= 16 ? 4 : 1;
@@ -767,8 +790,8 @@ int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const
     if (e != hipSuccess) { mk_set_error("mk_ransac_hypotheses: cannot reserve %zu B of LDS", lds); return MK_ERR_LAUNCH; }
   }
   hipLaunchKernelGGL(hypotheses_kernel, dim3(nsets * nsplit), dim3(256), lds, (hipStream_t)stream, X, Y, wts, noise3, idx3_in,
-                     (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), th_soft, Rh, th, score,
-                     idx3, it_ransac, k, nsplit);
+                     (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), offset_dev, th_soft, Rh, th,
+                     score, idx3, it_ransac, k, nsplit);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

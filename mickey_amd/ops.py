@@ -197,7 +197,12 @@ def mutual_nn(scores):
 
 # ---- solver ---------------------------------------------------------------------------------------
 
-def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None):
+def counter_add(counter, inc):
+    """counter (int64 CUDA tensor, 1 element) += inc on the current stream (see mk_counter_add)."""
+    call("mk_counter_add", ptr(counter), int(inc), stream())
+
+
+def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None):
     """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
     p, noise = _c(p, noise)
     _chk(p, torch.float32)
@@ -206,8 +211,8 @@ def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None
     idx = torch.empty((B * rows_per_pair, k), device=dev, dtype=torch.int32)
     cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
     work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k),), device=dev, dtype=torch.uint8)
-    call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(idx), ptr(cnt), ptr(invalid), ptr(work), B, rows_per_pair,
-         ncell, k, stream())
+    call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(offset_dev), ptr(idx), ptr(cnt), ptr(invalid), ptr(work),
+         B, rows_per_pair, ncell, k, stream())
     return idx, cnt
 
 
@@ -230,7 +235,7 @@ def gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, ro
     return X, Y, wts, corr
 
 
-def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0):
+def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0, offset_dev=None):
     X, Y, wts, noise3, idx3_in = _c(X, Y, wts, noise3, idx3_in)
     nsets, k, _ = X.shape
     dev = X.device
@@ -239,8 +244,8 @@ def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, 
     th = torch.empty((nh, 3), device=dev, dtype=torch.float32)
     score = torch.empty((nh,), device=dev, dtype=torch.float32)
     idx3 = torch.empty((nh, 3), device=dev, dtype=torch.int32)
-    call("mk_ransac_hypotheses", ptr(X), ptr(Y), ptr(wts), ptr(noise3), ptr(idx3_in), int(seed), int(offset), float(th_soft),
-         ptr(Rh), ptr(th), ptr(score), ptr(idx3), nsets, it_ransac, k, stream())
+    call("mk_ransac_hypotheses", ptr(X), ptr(Y), ptr(wts), ptr(noise3), ptr(idx3_in), int(seed), int(offset), ptr(offset_dev),
+         float(th_soft), ptr(Rh), ptr(th), ptr(score), ptr(idx3), nsets, it_ransac, k, stream())
     return Rh, th, score, idx3
 
 
