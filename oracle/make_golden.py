@@ -166,6 +166,29 @@ def gold_solver(cfg, model):
     assert float(Rz.abs().sum()) == 0 and float(Rzo.abs().sum()) == 0 and float(czo.abs().sum()) == 0
 
 
+def golden_submission_lines():
+    """tests/golden/submission_lines.npz: text lines produced by the REFERENCE's own `Pose.__str__` (the dataclass is
+    exec'd from submission.py:16-29; the module itself does not import here because transforms3d is absent)."""
+    import re
+    src = open(os.path.join(ref_shim.REF_ROOT if hasattr(ref_shim, "REF_ROOT") else "/root/reference", "submission.py")).read()
+    m = re.search(r"@dataclass\nclass Pose:.*?\n\n\n", src, re.S)
+    ns = {"np": np}
+    exec("from dataclasses import dataclass\n" + m.group(0), ns)
+    rng = np.random.default_rng(7)
+    names, qs, ts, inl, lines = [], [], [], [], []
+    for i in range(16):
+        q = rng.normal(size=4).astype(np.float32)
+        q /= np.linalg.norm(q)
+        t = (rng.normal(size=3) * 10.0 ** rng.integers(-3, 2)).astype(np.float32)
+        c = float(np.float32(rng.uniform(0, 400)))
+        name = "seq1/frame_%05d.jpg" % (i * 37)
+        names.append(name); qs.append(q); ts.append(t); inl.append(c)
+        lines.append(str(ns["Pose"](image_name=name, q=q, t=t, inliers=c)))
+    np.savez(os.path.join(GOLD, "submission_lines.npz"), names=np.array(names), q=np.stack(qs), t=np.stack(ts),
+             inliers=np.array(inl, dtype=np.float64), lines=np.array(lines))
+    print("submission_lines: %d lines, e.g. %s" % (len(lines), lines[0]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -174,8 +197,10 @@ def main():
     model = gold_full_forward(cfg)
     gold_matcher(cfg, model)
     gold_solver(cfg, model)
+    golden_submission_lines()
     print("golden fixtures written to", GOLD)
 
 
 if __name__ == "__main__":
     main()
+
