@@ -58,10 +58,12 @@ def test_gemm_bias_act(dtype, M, N, K, tile):
     assert torch.equal(out.cpu(), w.float()[:, :64].t().contiguous())
 
 
-def test_gemm_ls_residual():
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 7])
+@pytest.mark.parametrize("M,N,K", [(3878, 1024, 4096), (700, 384, 256)])
+def test_gemm_ls_residual(M, N, K, tile):
     from mickey_amd import ops
     dev = _dev()
-    M, N, K = 3878, 1024, 4096
+    ops.gemm_set_tile(tile)
     a = (torch.randn((M, K), generator=g(1)) * 0.5).bfloat16()
     w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).bfloat16()
     bias, gamma = torch.randn((N,), generator=g(3)), torch.rand((N,), generator=g(4))
@@ -97,10 +99,12 @@ def test_gemm_qkv_layout(tile):
     assert float(q[:, :, ntok:].abs().sum()) == 0.0  # pad rows untouched
 
 
-def test_patch_embed_and_cls():
+@pytest.mark.parametrize("tile", [0, 2, 5, 7])
+@pytest.mark.parametrize("nimg,H,W,D", [(2, 75, 101, 256), (3, 300, 290, 384)])   # 5 x 7 and 21 x 20 patches
+def test_patch_embed_and_cls(nimg, H, W, D, tile):
     from mickey_amd import ops
     dev = _dev()
-    nimg, H, W, D = 2, 75, 101, 256   # cropped to 70 x 98 -> 5 x 7 patches
+    ops.gemm_set_tile(tile)
     gh, gw = H // 14, W // 14
     img = torch.rand((nimg, 3, H, W), generator=g(1))
     wconv = torch.randn((D, 3, 14, 14), generator=g(2)) / math.sqrt(588)
@@ -292,6 +296,25 @@ def test_dual_softmax_vs_oracle(n0, n1):
     # no dustbin
     sc2, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, None, want_kp=False, want_final=False)
     assert rel(sc2, O.dual_softmax(d0, d1, None, 0.1)) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,n0,n1", [(3, 64, 77, 200), (9, 128, 97, 64), (1, 32, 33, 31)])
+def test_dual_softmax_other_shapes(B, C, n0, n1):
+    """Descriptor widths below 128 (the generic-C instantiation), ragged n0 != n1 not multiples of 32, and B >= 8 (the
+    XCD-local workgroup decode) against the oracle."""
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    d0 = F.normalize(torch.randn((B, C, n0), generator=g(31)), dim=1)
+    d1 = F.normalize(torch.randn((B, C, n1), generator=g(32)), dim=1)
+    s0 = torch.rand((B, 1, n0), generator=g(33)) / n0
+    s1 = torch.rand((B, 1, n1), generator=g(34)) / n1
+    ref = O.dual_softmax(d0, d1, 1.0, 0.1)
+    kp_ref = torch.matmul(s0.transpose(2, 1), s1)
+    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 1.0)
+    assert rel(sc, ref) < 1e-5, rel(sc, ref)
+    assert torch.equal(kp.cpu(), kp_ref)
+    assert rel(fin, ref * kp_ref) < 1e-5
 
 
 def test_matcher_golden(golden):

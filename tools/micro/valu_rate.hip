@@ -3,6 +3,30 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// 16 independent 2-wide chains: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 throughput
+template <int KIND>
+__global__ void kp(float* out, long long* cyc, int iters) {
+  f32x2 x[16];
+  for (int i = 0; i < 16; ++i) x[i] = f32x2{threadIdx.x * 1e-3f + i, 1.0f + i};
+  const f32x2 c = f32x2{1.0001f, 0.9999f}, d = f32x2{0.5f, 0.25f};
+  long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (KIND == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(d));
+      if (KIND == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+      if (KIND == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c), "v"(d));
+    }
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += x[i][0] + x[i][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
 template <int KIND>
 __global__ void k(float* out, long long* cyc, int iters) {
   float x[16], y[16];
@@ -23,7 +47,7 @@ __global__ void k(float* out, long long* cyc, int iters) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
-template <int KIND>
+template <int KIND, bool PK = false>
 void run(const char* name, int threads) {
   float* out;
   long long* cyc;
@@ -33,9 +57,11 @@ void run(const char* name, int threads) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, 100);
+  if (PK) hipLaunchKernelGGL((kp<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, 100);
+  else hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, 100);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  if (PK) hipLaunchKernelGGL((kp<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  else hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
   (void)hipEventRecord(e1);
   (void)hipDeviceSynchronize();
   float ms;
@@ -54,5 +80,8 @@ int main() {
   for (int w = 1; w <= 4; ++w) run<1>("fma", 256 * w);
   for (int w = 1; w <= 4; ++w) run<2>("exp + fma", 256 * w);
   for (int w = 1; w <= 4; ++w) run<3>("exp + 2 fma + max", 256 * w);
+  for (int w = 1; w <= 4; w *= 2) run<0, true>("v_pk_add_f32", 256 * w);
+  for (int w = 1; w <= 4; w *= 2) run<1, true>("v_pk_mul_f32", 256 * w);
+  for (int w = 1; w <= 4; w *= 2) run<2, true>("v_pk_fma_f32", 256 * w);
   return 0;
 }
