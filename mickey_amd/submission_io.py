@@ -31,20 +31,23 @@ def mat2quat(M):
     return q
 
 
+def _fields(values):
+    """Space-separated fixed-point fields with 6 decimals: what numpy's array2string prints for the reference's
+    formatter, without going through array2string."""
+    return ' '.join('%.6f' % float(v) for v in np.asarray(values).reshape(-1))
+
+
 @dataclass
 class Pose:
-    """One line of `pose_{scene}.txt`: `name qw qx qy qz tx ty tz conf` (submission.py:17-29)."""
+    """One line of `pose_{scene}.txt`: `name qw qx qy qz tx ty tz conf` (reference submission.py:17-29).  The confidence is
+    printed with Python's shortest round-trip float repr, as the reference's f-string does."""
     image_name: str
     q: np.ndarray
     t: np.ndarray
     inliers: float
 
-    def __str__(self) -> str:
-        formatter = {'float': lambda v: f'{v:.6f}'}
-        max_line_width = 1000
-        q_str = np.array2string(self.q, formatter=formatter, max_line_width=max_line_width)[1:-1]
-        t_str = np.array2string(self.t, formatter=formatter, max_line_width=max_line_width)[1:-1]
-        return f'{self.image_name} {q_str} {t_str} {self.inliers}'
+    def __str__(self):
+        return ' '.join((self.image_name, _fields(self.q), _fields(self.t), str(self.inliers)))
 
 
 def append_batch(results_dict, scene_ids, query_names, R, t, inliers):
