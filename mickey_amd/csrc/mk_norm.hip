@@ -9,11 +9,12 @@
 namespace {
 using namespace mk;
 
-constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048 (instantiated for 4 as well: D <= 1024 needs half the registers)
 
 constexpr int LN_RPW = 4;   // rows per wave: the loads of row r+1 are in flight while row r is reduced and stored
+                            // (a third buffer / 6 rows per wave measured 7 % slower in the forward)
 
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
@@ -22,23 +23,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
   if (r0 >= rows_out) return;
   const int rpo = rows_per_img - skip;
-  f32x4 v[2][LN_MAXV];
-  auto load_row = [&](int r, f32x4 (&dst)[LN_MAXV]) {
+  f32x4 v[2][MAXV];
+  auto load_row = [&](int r, f32x4 (&dst)[MAXV]) {
     const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
     const float* xr = x + rin * ldx;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) dst[i] = *(const f32x4*)(xr + c);
     }
   };
   load_row(r0, v[0]);
+  // weight / bias shared by all rows (the encoder's case): once per wave, not once per row -- the compiler cannot hoist
+  // them itself because `out` may alias them for all it knows (8 of the 12 load instructions per row)
+  f32x4 wreg[MAXV], breg[MAXV];
+  const bool shared_wb = wgroup_rows <= 0;
+  if (shared_wb) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        wreg[i] = *(const f32x4*)(w + c);
+        breg[i] = *(const f32x4*)(b + c);
+      }
+    }
+  }
 #pragma unroll
   for (int rr = 0; rr < LN_RPW; ++rr) {
     const int r = r0 + rr;
     if (r >= rows_out) break;
     if (rr + 1 < LN_RPW && r + 1 < rows_out) load_row(r + 1, v[(rr + 1) & 1]);
-    f32x4 (&cur)[LN_MAXV] = v[rr & 1];
+    f32x4 (&cur)[MAXV] = v[rr & 1];
     const float* wr = w;
     const float* br = b;
     if (wgroup_rows > 0) {  // one (w, b) per block of wgroup_rows output rows
@@ -47,14 +62,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) s += (cur[i][0] + cur[i][1]) + (cur[i][2] + cur[i][3]);
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
 #pragma unroll
@@ -66,10 +81,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
-        const f32x4 ww = *(const f32x4*)(wr + c), bb = *(const f32x4*)(br + c);
+        const f32x4 ww = shared_wb ? wreg[i] : *(const f32x4*)(wr + c), bb = shared_wb ? breg[i] : *(const f32x4*)(br + c);
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (cur[i][e] - mean) * rstd * ww[e] + bb[e];
@@ -154,12 +169,15 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
   MK_CHECK_ARG(rows_out > 0 && rows_per_img > skip && skip >= 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
                "mk_layernorm: bad geometry");
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
-  if (dtype == MK_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
-                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo,
-                       out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows);
+#define MK_LN(T_, V_)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows)
+  if (dtype == MK_BF16) {
+    if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
+  } else {
+    if (D <= 1024) MK_LN(_Float16, 4); else MK_LN(_Float16, LN_MAXV);
+  }
+#undef MK_LN
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
