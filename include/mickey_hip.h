@@ -47,7 +47,8 @@ int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, v
 /* Schedule selection of the GEMM/conv kernel: 0 = automatic (128x128 two-stage for small problems, the 256x256
  * full-line ping-pong schedule for large ones), 1 = force 128x128, 2 = force the 256x256 persistent K-stream kernel,
  * 3 = force the K=32 ping-pong ring, 4 = automatic with schedule 2 for large problems, 5/7/8/9 = full-line
- * ping-pong variants (persistent / banded tile order on or off), 10..21 = timing ablations (wrong results).
+ * ping-pong variants (persistent / banded tile order on or off); 10..21 = timing ablations (wrong results; only when
+ * built with -DMK_GEMM_ABLATIONS).
  * Process-wide; for benchmarks and tests. */
 int mk_gemm_set_tile(int mode);
 

@@ -1307,6 +1307,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   }
   if (g_force_tile == 3)
     return dtype == MK_BF16 ? launch_pp<__bf16, AMODE>(p, groups, st) : launch_pp<_Float16, AMODE>(p, groups, st);
+#ifdef MK_GEMM_ABLATIONS   // timing ablations of the K=32 ring kernel for tools/ablate_gemm.py (results are wrong); not in the default build
   if (g_force_tile >= 10 && g_force_tile < 22 && AMODE == A_DENSE && dtype == MK_BF16) {  // timing ablations (wrong results)
     switch (g_force_tile - 10) {
       case 1: return launch_pp<__bf16, A_DENSE, 1>(p, groups, st);
@@ -1323,6 +1324,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
       default: break;
     }
   }
+#endif
   if (dtype == MK_BF16)
     return big ? launch_cfg<__bf16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<__bf16, AMODE, 4, 2, 2>(p, groups, st);
   return big ? launch_cfg<_Float16, AMODE, 8, 2, 4>(p, groups, st) : launch_cfg<_Float16, AMODE, 4, 2, 2>(p, groups, st);
@@ -1352,7 +1354,11 @@ int mk_gemm_set_tile(int mode) {
     g_stagger_us = mode - 100;
     return MK_OK;
   }
-  MK_CHECK_ARG((mode >= 0 && mode <= 9) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: mode must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256 ping-pong)");
+  #ifdef MK_GEMM_ABLATIONS
+  MK_CHECK_ARG((mode >= 0 && mode <= 9) || (mode >= 10 && mode < 22), "mk_gemm_set_tile: unknown mode %d", mode);
+#else
+  MK_CHECK_ARG(mode >= 0 && mode <= 9, "mk_gemm_set_tile: unknown mode %d (0 auto, 1..5 / 7..9 schedules; ablations need -DMK_GEMM_ABLATIONS)", mode);
+#endif
   g_force_tile = mode;
   return MK_OK;
 }

@@ -1,3 +1,5 @@
+"""GEMM timing ablations of the K=32 ring kernel (dev tool).  Needs a library built with -DMK_GEMM_ABLATIONS: those
+instantiations are not in the default build."""
 import sys, os, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mickey_amd import ops
