@@ -66,3 +66,35 @@ def test_submission_zip_round_trip(tmp_path):
                 Rc2w = Rotation.from_quat([q_c2w[1], q_c2w[2], q_c2w[3], q_c2w[0]]).as_matrix()
                 assert np.abs(Rc2w - R.T).max() < 1e-4
     assert seen == len(truth) == 11
+
+
+def test_predict_with_stub_model(tmp_path):
+    """The reference's predict loop (submission.py:32-61) on a stub model: batches are walked in order, `inliers` is read
+    from the data dict the model filled, NaN poses are dropped, scenes are grouped."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from mickey_amd.submission_io import load_poses, predict, save_submission
+
+    class Stub(torch.nn.Module):
+        def forward(self, data):
+            B = len(data["scene_id"])
+            R = torch.from_numpy(Rotation.random(B, random_state=int(data["seed"])).as_matrix()).float()
+            t = torch.full((B, 1, 3), float(data["seed"]))
+            if data["seed"] == 2:
+                t[0] = float("nan")
+            data["inliers"] = torch.arange(B, dtype=torch.float32).reshape(B, 1) + 10 * data["seed"]
+            return R, t
+
+    loader = [{"scene_id": ["s00001", "s00002", "s00001"], "seed": s,
+               "pair_names": (["seq0/frame_00000.jpg"] * 3, ["seq1/frame_%05d.jpg" % (10 * s + i) for i in range(3)])}
+              for s in (1, 2, 3)]
+    moved = []
+    res = predict(loader, Stub(), to_device=lambda d, m: (moved.append(1), d)[1])
+    assert len(moved) == 3 and sorted(res) == ["s00001", "s00002"]
+    assert [p.image_name[-9:-4] for p in res["s00001"]] == ["00010", "00012", "00022", "00030", "00032"]   # 00020 was NaN
+    assert [p.inliers for p in res["s00002"]] == [11.0, 21.0, 31.0]
+    path = save_submission(res, tmp_path / "submission.zip")
+    import zipfile
+    with zipfile.ZipFile(path) as zf:
+        lines = zf.read("pose_s00002.txt").decode().split("\n")
+    assert len(lines) == 3 and set(load_poses(lines)) == {11, 21, 31}

@@ -1,5 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "layernorm or norm" 2>&1 | tail -2
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof -o b32 -- python /root/repo/bench.py --no-cpu-baseline --no-kernel-events --steps 3 --warmup 1 > /root/repo/gpurun_out/prof_bench.log 2>&1
+for b in 1 4 8; do for t in 0 7; do
+  timeout 200 python bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline --gemm-tile $t 2>&1 | tail -1 > gpurun_out/ab.json
+  python - <<PY
+import json; d=json.load(open("gpurun_out/ab.json")); print("B=$b tile=$t", round(d["value"],1), "pairs/s", round(d["ms_per_step"],2), "ms", round(d["roofline"]["achieved"],1), "TF")
+PY
+done; done
