@@ -25,7 +25,8 @@ constexpr int KV_TILE_BYTES = 64 * 64 * 2;  // 8 KiB
 
 // QB = 32-query sub-blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs
 // and a workgroup covers 256 queries per staged K/V tile (half the LDS-DMA, ds_read and barrier work per MFMA).
-template <typename T, int QB>
+// ABL (timing ablations, wrong results): 1 = no per-tile barrier, 2 = no per-tile barrier and no DMA wait
+template <typename T, int QB, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ vt, T* __restrict__ out, int ldo, int heads,
                                                           int ntok, int ntok_pad) {
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   // the VALU work of a loop that is VALU-bound).
   auto kv_tile = [&](const int kt, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (ABL < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ABL < 1) __syncthreads();
     if (!LAST) stage((kt + 1) & 1, kt + 1);
     const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
@@ -516,6 +517,17 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
                        (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
     return;
   }
+#ifdef MK_ATTN_ABLATIONS
+  if (g_attn_mode == 13 || g_attn_mode == 14) {
+    if (g_attn_mode == 13)
+      hipLaunchKernelGGL((attn_fwd_kernel<T, 2, 1>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
+                         (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<T, 2, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
+                         (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+    return;
+  }
+#endif
   if (g_attn_mode == 2 || (g_attn_mode == 0 && blocks2 >= 512))
     hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
@@ -527,6 +539,9 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }  // namespace
 
 extern "C" int mk_attn_set_mode(int mode) {
+  #ifdef MK_ATTN_ABLATIONS
+  if (mode == 13 || mode == 14) { g_attn_mode = mode; return MK_OK; }
+#endif
   MK_CHECK_ARG(mode >= 0 && mode <= 5, "mk_attn_set_mode: 0 auto, 1 = 32 q/wave, 2 = 64 q/wave, 3 = pipelined, 4 = VALU-lean, 5 = VALU-lean 8 waves");
   g_attn_mode = mode;
   return MK_OK;
