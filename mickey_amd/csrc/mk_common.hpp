@@ -81,6 +81,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(MK_GLOBAL_PTR(gsrc), MK_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
+// same with cache-policy bits (gfx940+ encoding: 1 = sc0, 2 = nt, 16 = sc1); AUX must be a compile-time constant
+template <int AUX>
+__device__ __forceinline__ void glds16_cp(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(MK_GLOBAL_PTR(gsrc), MK_LDS_PTR(lds_wave_base), 16, 0, AUX);
+}
 
 // XOR swizzle of 16-byte chunks inside 128-byte LDS rows: chunk' = chunk ^ ((row >> 1) & 7).
 // Conflict-free for ds_read_b128 fragment reads where a 16-lane group covers 16 distinct rows at one

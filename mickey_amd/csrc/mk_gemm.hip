@@ -965,8 +965,11 @@ __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_
 
 // DBG: dev-only instantiation that records per wave-row {entry, first stage landed, K loop done, epilogue issued}
 // on the 100-MHz wall clock plus HW_ID / XCC_ID of the first tile a workgroup runs (tools/gemm_timeline.py)
-template <typename T, int AMODE, bool PERSIST, bool DBG = false>
+// ABL (experiments, -DMK_PP64_ABLATIONS): 1 = no LDS-DMA inside the K loop, 2 = fragments read once, 4 = no barriers
+// (1, 2, 4: wrong results); cache policy of the DMA loads (results stay correct): 8 = A nt, 16 = W nt, 32 = sc0, 64 = sc0 sc1
+template <typename T, int AMODE, bool PERSIST, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m, int stagger, unsigned long long* dbg) {
+  bool abl_loop = false, abl_loaded = false;
   unsigned long long t_entry = 0, t_landed = 0, t_loop = 0;
   if (DBG) t_entry = __builtin_amdgcn_s_memrealtime();
   // All CUs start together and would hit their (HBM-heavy, un-overlapped) epilogues in lockstep while HBM idles during
@@ -1028,19 +1031,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   };
   // s = stage index relative to the current tile; s >= nk addresses the next tile (registers already switched)
   auto dma_w = [&](int s, int pb, bool more) {   // 4 instructions
+    if ((ABL & 1) && abl_loop) return;
     if (s >= nk && !more) return;
     char* sW = smem + ((pb + s) & 1) * STAGE_BYTES + A_BYTES;
     const int k0 = (s < nk ? s : s - nk) * BK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(W + (woff[j] + (unsigned)k0), sW + (wave * 4 + j) * 1024);
+    for (int j = 0; j < 4; ++j) glds16_cp<(ABL & 16) ? 2 : (ABL & 32) ? 1 : (ABL & 64) ? 17 : 0>(W + (woff[j] + (unsigned)k0), sW + (wave * 4 + j) * 1024);
   };
   auto dma_a = [&](int s, int pb, bool more) {   // 4 instructions
+    if ((ABL & 1) && abl_loop) return;
     if (s >= nk && !more) return;
     char* sA = smem + ((pb + s) & 1) * STAGE_BYTES;
     const int k0 = (s < nk ? s : s - nk) * BK;
     if (AMODE == A_DENSE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) glds16(A + (aoff[j] + (unsigned)k0), sA + (wm * 16 + wn * 4 + j) * 1024);
+      for (int j = 0; j < 4; ++j) glds16_cp<(ABL & 8) ? 2 : (ABL & 32) ? 1 : (ABL & 64) ? 17 : 0>(A + (aoff[j] + (unsigned)k0), sA + (wm * 16 + wn * 4 + j) * 1024);
     } else {
       const int kc = 9 * p.C1;
       const T* src;
@@ -1071,6 +1076,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
 
   const int fr = lane & 15, fg = lane >> 4;
   auto load_frags = [&](V8* wf, V8* xf, int par, int h) {
+    if ((ABL & 2) && abl_loaded) return;
+    abl_loaded = true;
     const char* sA = smem + par * STAGE_BYTES;
     const char* sW = sA + A_BYTES;
 #pragma unroll
@@ -1094,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   };
   auto bar = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
   };
 
   // next-tile addresses must be computed in the K-loop iteration that switches to them: hoisted in front of the loop
@@ -1114,6 +1121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   dma_w(0, 0, false);
   dma_a(1, 0, false);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  abl_loop = true;
   if (DBG) t_landed = __builtin_amdgcn_s_memrealtime();
   int pb = 0;   // LDS stage parity of the current tile's stage 0
   if (wm == 1) bar();   // slot 0: this wave-row idles
@@ -1213,12 +1221,12 @@ int num_cus() {
 unsigned long long* g_dbg = nullptr;   // mk_gemm_debug_timeline
 int g_stagger_us = 0;                  // start-time spread of the first workgroup round for RMW epilogues (set_tile 100+us)
 
-template <typename T, int AMODE, bool PERSIST, bool DBG = false>
+template <typename T, int AMODE, bool PERSIST, bool DBG = false, int ABL = 0>
 int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   constexpr int LDS = 2 * 512 * 128 + (PERSIST ? 8 * 4096 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, PERSIST, DBG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -1229,7 +1237,7 @@ int launch_pp64(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   const int cap = (num_cus() + groups - 1) / groups;   // one resident workgroup per CU in total
   const int gx = (!PERSIST || ntm * ntn < cap) ? ntm * ntn : cap;
   const int stagger = (p.epi == MK_EPI_LS_RESIDUAL && ntm * ntn >= 4 * cap) ? g_stagger_us * 100 : 0;
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, PERSIST, DBG>), dim3(gx, groups, 1), dim3(512), LDS, st, p, band_m, stagger, g_dbg);
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, PERSIST, DBG, ABL>), dim3(gx, groups, 1), dim3(512), LDS, st, p, band_m, stagger, g_dbg);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -1288,6 +1296,20 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
   if (g_force_tile == 1) big = false;
   if (g_force_tile == 2) big = true;
+#ifdef MK_PP64_ABLATIONS
+  if (g_force_tile >= 30 && g_force_tile <= 39 && AMODE == A_DENSE && dtype == MK_BF16) {
+    switch (g_force_tile - 30) {
+      case 1: return launch_pp64<__bf16, A_DENSE, false, false, 1>(p, groups, st, 8);
+      case 3: return launch_pp64<__bf16, A_DENSE, false, false, 3>(p, groups, st, 8);
+      case 4: return launch_pp64<__bf16, A_DENSE, false, false, 4>(p, groups, st, 8);
+      case 5: return launch_pp64<__bf16, A_DENSE, false, false, 8>(p, groups, st, 8);    // A nt
+      case 6: return launch_pp64<__bf16, A_DENSE, false, false, 24>(p, groups, st, 8);   // A and W nt
+      case 7: return launch_pp64<__bf16, A_DENSE, false, false, 32>(p, groups, st, 8);   // sc0
+      case 8: return launch_pp64<__bf16, A_DENSE, false, false, 64>(p, groups, st, 8);   // sc0 sc1
+      default: return launch_pp64<__bf16, A_DENSE, false, false, 16>(p, groups, st, 8);  // W nt
+    }
+  }
+#endif
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
                     (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
   const bool forced64 = g_force_tile == 5 || (g_force_tile >= 7 && g_force_tile <= 9);
@@ -1350,6 +1372,9 @@ int mk_gemm_debug_timeline(void* buf) {
 }
 
 int mk_gemm_set_tile(int mode) {
+#ifdef MK_PP64_ABLATIONS
+  if (mode >= 30 && mode <= 39) { g_force_tile = mode; return MK_OK; }
+#endif
   if (mode >= 100 && mode < 400) {   // dev: stagger window in microseconds
     g_stagger_us = mode - 100;
     return MK_OK;
