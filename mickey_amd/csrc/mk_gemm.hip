@@ -1219,6 +1219,7 @@ int num_cus() {
 }
 
 unsigned long long* g_dbg = nullptr;   // mk_gemm_debug_timeline
+int g_band_m = 8;                      // m-tiles per band of the tile order (set_tile 400+b)
 int g_stagger_us = 0;                  // start-time spread of the first workgroup round for RMW epilogues (set_tile 100+us)
 
 template <typename T, int AMODE, bool PERSIST, bool DBG = false, int ABL = 0>
@@ -1317,7 +1318,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
     // auto (0/6) and 7: one tile per workgroup, bands of 8 m-tiles (measured best: 6-16 % over the K=32 ring and the
     // K-stream kernel, 8-10 % over its own persistent variant); 5: persistent + bands; 8: persistent, row-major; 9: neither
     const bool persist = g_force_tile == 5 || g_force_tile == 8;
-    const int band_m = (g_force_tile == 8 || g_force_tile == 9) ? 1 : 8;
+    const int band_m = (g_force_tile == 8 || g_force_tile == 9) ? 1 : g_band_m;
     if (g_dbg && AMODE == A_DENSE && dtype == MK_BF16 && groups == 1)
       return persist ? launch_pp64<__bf16, A_DENSE, true, true>(p, groups, st, band_m)
                      : launch_pp64<__bf16, A_DENSE, false, true>(p, groups, st, band_m);
@@ -1375,6 +1376,10 @@ int mk_gemm_set_tile(int mode) {
 #ifdef MK_PP64_ABLATIONS
   if (mode >= 30 && mode <= 39) { g_force_tile = mode; return MK_OK; }
 #endif
+  if (mode >= 400 && mode < 528) {   // dev: band height of the tile order
+    g_band_m = mode - 400 > 0 ? mode - 400 : 1;
+    return MK_OK;
+  }
   if (mode >= 100 && mode < 400) {   // dev: stagger window in microseconds
     g_stagger_us = mode - 100;
     return MK_OK;

@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 300 python tools/bench_gemm.py 7 35 39 36 37 38 2>&1 | tail -6
+timeout 300 python tools/bench_gemm.py 408 404 416 432 402 2>&1 | tail -5
