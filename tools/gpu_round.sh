@@ -1,28 +1,12 @@
 #!/bin/bash
-# PMC refresh for the current GEMM (schedules 2 and 7) and attention kernels: separate rocprofv3 --pmc passes
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out
-cd /tmp
-for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "GRBM_GUI_ACTIVE" "SQ_INSTS_MFMA SQ_INSTS_LDS"; do
-  tag=$(echo $c | tr ' ' '_')
-  rm -rf /tmp/pg_$tag /tmp/pa_$tag
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pg_$tag -o p -- python $R/tools/pmc_gemm.py > /tmp/pg.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pa_$tag -o p -- python $R/tools/pmc_attn.py > /tmp/pa.log 2>&1
-done
-python - <<'PY'
-import csv, glob, collections, json, os
-out = collections.defaultdict(dict)
-for d in glob.glob("/tmp/pg_*") + glob.glob("/tmp/pa_*"):
-    fs = glob.glob(d + "/*counter_collection.csv")
-    if not fs: continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
-        k = r["Kernel_Name"]
-        name = "gemm_pp64 (schedule 7)" if "gemm_pp64" in k else "gemm_kernel 256x256 K-stream (schedule 2)" if ("gemm_kernel" in k and "Li8ELi2ELi4" in k) else "attn_fwd_kernel<bf16,2>" if "attn_fwd" in k else None
-        if name: acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (name, cn), v in acc.items():
-        out[name][cn] = sum(v) / len(v)
-json.dump(out, open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_busy.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
-PY
+# One GPU visit (rewritten per experiment during development).  This version: verification of the committed state --
+# full GPU tests, smoke, rocprofv3 kernel statistics of bench.py, bench lines at B = 32 and B = 1 into gpurun_out/.
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -3 > gpurun_out/r01_pytest_gpu.txt
+cat gpurun_out/r01_pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof -o b32 -- python /root/repo/bench.py --no-cpu-baseline --no-kernel-events --steps 3 --warmup 1 > /root/repo/gpurun_out/prof_bench.log 2>&1
+cd /root/repo
+timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/bench_b32.json
+timeout 300 python bench.py --batch 1 --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_b1.json
