@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   const T* Vh = vt + hb * 64 * ntok_pad;
   const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
   const int j = lane & 31, hi = lane >> 5;
+  // 1939 tokens are padded to a multiple of the query block: in the last block whole waves hold no valid query (1/32 of
+  // all waves at 256 queries per block); they skip the MFMA / softmax work
+  const bool wave_has_queries = q0 < ntok;
 
   V8 qf[QB][4];
 #pragma unroll
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     if (ABL < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ABL < 1) __syncthreads();
     if (!LAST) stage((kt + 1) & 1, kt + 1);
+    if (!wave_has_queries) return;   // pad-only wave of the last query block: stages K/V and keeps the barriers, nothing else
     const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
 
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 3 : 2) void attn_fwd_lea
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    if (q0 >= ntok) continue;   // pad-only wave of the last query block: stages K/V and keeps the barriers, nothing else
     const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
     const char* sV = sK + KV_TILE_BYTES;
 
