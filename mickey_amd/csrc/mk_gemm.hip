@@ -572,6 +572,25 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
   const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
   const int nw = n0 + wn * 64;        // first feature of this wave's block
   const int mw = m0 + wm * 128;       // first row
+  // qkv split: (image, token) of row mw + r without a per-row integer division (~25 VALU incl. quarter-rate ops, 16 per
+  // lane before): one wave-uniform division; the wave's 128 rows cross at most one image boundary when ntok >= 128
+  int img0 = 0, tok0 = 0;
+  if (EPI == MK_EPI_QKV) {
+    img0 = mw / p.ntok;
+    tok0 = mw - img0 * p.ntok;
+  }
+  auto img_tok = [&](int r, int& img, int& tok) {
+    if (p.ntok >= 128) {
+      const int t = tok0 + r;
+      const bool wrap = t >= p.ntok;
+      img = img0 + (wrap ? 1 : 0);
+      tok = wrap ? t - p.ntok : t;
+    } else {
+      const int m = mw + r;
+      img = m / p.ntok;
+      tok = m - img * p.ntok;
+    }
+  };
   f32x4 bv[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -590,7 +609,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         for (int mi = 0; mi < 8; ++mi) {
           const int m = mw + mi * 16 + fr;
           if (m >= p.M) continue;
-          const int img = m / p.ntok, tok = m - img * p.ntok;
+          int img, tok;
+          img_tok(mi * 16 + fr, img, tok);
           const long long hb = (long long)img * p.heads + head;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
@@ -645,7 +665,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
       if (m >= p.M || n >= p.N) continue;
       T* dst;
       if (EPI == MK_EPI_QKV) {
-        const int img = m / p.ntok, tok = m - img * p.ntok;
+        int img, tok;
+        img_tok(r, img, tok);
         dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
       } else {
         dst = (T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n;
