@@ -3,35 +3,45 @@
 One "step" = one full MickeyRelativePose.forward (ViT-L/14 encoder + 4 heads for both images,
 dual-softmax matcher, 20x100-hypothesis probabilistic-Procrustes RANSAC) over a batch of B synthetic
 540x720 (W x H) image pairs per GPU, inputs already resident in HBM, followed by the single RCCL
-all-gather of the poses when N > 1.  Weak scaling: every rank processes its own B pairs.
+all-gather of the poses when N > 1 (issued on a side stream, waited for before the step's results are
+read).  Weak scaling: every rank processes its own B pairs.
+
+``--gpus N`` with N > 1 launches N ranks itself (one process per GPU through torch.distributed.run,
+rendezvous on 127.0.0.1) unless the script already runs under torch.distributed.run; it fails loudly when
+the node has fewer than N GPUs.  ``n_gpus`` in the output is the number of ranks RCCL saw.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with
   roofline     -- the dominant kernel (the 16-bit MFMA GEMM of the encoder linears): algorithmic FLOPs of
-                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s
+                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s;
+                  roofline.stages lists every stage the same way (attention, conv-GEMM, LayerNorm, matcher,
+                  sampler against their governing peak; hypotheses / refinement: time only)
   cpu_baseline -- the CPU oracle (torch-CPU fp32 restatement of the reference) timed on this box's host
-                  cores on a bounded sample (1 pair), N = 1 only
+                  cores on a bounded sample (1 pair; 1 warm-up + median of 3, per stage), N = 1 only
+  alt          -- the same workload with fp16 operands (the reference's own low-precision mode), short run
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
+TRAFFIC_SOURCE = "profiles/r01_pmc_traffic.json"
 
 
 def pmc_traffic_bytes(batch):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of THIS workload
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_bench_traffic.sh; FETCH_SIZE doubled as the gfx950 note in
+    (TRAFFIC_SOURCE, produced by tools/pmc_bench_traffic.sh; FETCH_SIZE doubled as the gfx950 note in
     MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads).  Counters cannot be collected from inside the
-    timed run, so the figure is only reported for the batch size it was measured at."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    timed run, so the figure is a constant read from that file and only reported for the batch size it was measured at."""
+    path = os.path.join(ROOT, TRAFFIC_SOURCE)
     if batch != 32 or not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -41,18 +51,28 @@ def pmc_traffic_bytes(batch):
         return None
 
 
-class GemmProfiler:
-    """HIP-event timing of every encoder-linear GEMM launch on the stream it is launched on
-    (torch's current stream; ops.* launch there)."""
+class StageProfiler:
+    """HIP-event timing of every hot-path launch on the stream it is launched on (torch's current stream;
+    ops.* launch there), grouped into stages with their ALGORITHMIC work."""
+
+    # stage -> (governing bound, unit of work)
+    STAGES = {
+        "encoder_gemm": ("mfma", "flop"), "attention": ("mfma", "flop"), "conv_gemm": ("mfma", "flop"),
+        "head_gemm": ("mfma", "flop"), "layernorm": ("hbm", "byte"), "matcher": ("hbm", "byte"), "sampler": ("hbm", "byte"),
+        "hypotheses_refine": (None, None),
+    }
 
     def __init__(self):
-        self.records = []   # (flops, ev0, ev1)
+        self.records = []   # (stage, work, ev0, ev1)
         self.on = False
 
     def wrap(self, ops):
+        import torch
         prof = self
 
-        def timed(fn, flops_of):
+        def timed(name, stage, work_of):
+            fn = getattr(ops, name)
+
             def inner(*a, **k):
                 if not prof.on:
                     return fn(*a, **k)
@@ -60,39 +80,140 @@ class GemmProfiler:
                 e0.record()
                 out = fn(*a, **k)
                 e1.record()
-                prof.records.append((flops_of(*a, **k), e0, e1))
+                prof.records.append((stage, float(work_of(*a, **k)), e0, e1))
                 return out
-            return inner
-        ops.gemm = timed(ops.gemm, lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1])
-        ops.gemm_ls_residual = timed(ops.gemm_ls_residual, lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1])
-        ops.gemm_qkv = timed(ops.gemm_qkv, lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1])
+            setattr(ops, name, inner)
 
-    def summary(self):
-        if not self.records:
-            return None
-        fl = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return {"launches": len(self.records), "flops": fl, "ms": ms, "tflops": fl / (ms * 1e-3) / 1e12,
-                "avg_launch_ms": ms / len(self.records), "avg_launch_gflop": fl / len(self.records) / 1e9}
+        esz = lambda t: t.element_size()  # noqa: E731
+        mnk = lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1]  # noqa: E731
+        timed("gemm", "encoder_gemm", mnk)
+        timed("gemm_ls_residual", "encoder_gemm", mnk)
+        timed("gemm_qkv", "encoder_gemm", mnk)
+        timed("gemm_patch_embed", "encoder_gemm", mnk)
+        # attention.py:53-59: per (image, head) QK^T and PV, 2 * 2 * N^2 * 64
+        timed("flash_attn", "attention", lambda q, k, vt, out, nimg, heads, ntok, pad: 4.0 * nimg * heads * ntok * ntok * 64)
+        # implicit-GEMM 3x3 conv: 2 * M * Cout * (9 C1 + C2) per group
+        timed("conv3x3", "conv_gemm",
+              lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, zp, act=0, in2=None, C2=0, **k:
+              2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
+        timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k: 2.0 * groups * M * N * K)
+
+        def ln_bytes(x, w, b, eps, out=None, out_dtype=None, resid=None, rows_out=None, **k):
+            D = w.shape[-1]
+            rows = rows_out if rows_out is not None else x.numel() // x.shape[-1]
+            ob = esz(out) if out is not None else 2
+            return rows * D * (4 + ob + (4 if resid is not None else 0))
+        timed("layernorm", "layernorm", ln_bytes)
+
+        def match_bytes(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None, want_scores=True, want_kp=True,
+                        want_final=True):
+            B, C, n0 = dsc0.shape
+            n1 = dsc1.shape[2]
+            nout = int(want_scores) + int(want_kp and scr0 is not None) + int(want_final and scr0 is not None)
+            return 4.0 * B * (C * (n0 + n1) + nout * n0 * n1)
+        timed("dual_softmax", "matcher", match_bytes)
+        timed("sinkhorn", "matcher", lambda dsc0, dsc1, alpha, iters=10, *r, **k:
+              4.0 * dsc0.shape[0] * (2 * iters + 1) * (dsc0.shape[2] + 1) * (dsc1.shape[2] + 1))
+        timed("exprace_topk", "sampler", lambda p, rows, kk, **k: 4.0 * p.numel() + 4.0 * p.shape[0] * rows * kk)
+        for nm in ("gather_backproject", "ransac_hypotheses", "refine_pose"):
+            timed(nm, "hypotheses_refine", lambda *a, **k: 0.0)
+
+    def summary(self, steps):
+        by = {}
+        for stage, work, e0, e1 in self.records:
+            d = by.setdefault(stage, {"launches": 0, "work": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["work"] += work
+            d["ms"] += e0.elapsed_time(e1)
+        total_ms = sum(d["ms"] for d in by.values()) or 1.0
+        out = []
+        for stage, (bound, unit) in self.STAGES.items():
+            d = by.get(stage)
+            if not d:
+                continue
+            ent = {"stage": stage, "bound": bound, "launches_per_step": d["launches"] / steps, "ms_per_step": d["ms"] / steps,
+                   "share_of_kernel_time": d["ms"] / total_ms}
+            if bound == "mfma":
+                ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+                ent.update(achieved=ach, peak=PEAK_MFMA_TF, unit="TFLOP/s", frac=ach / PEAK_MFMA_TF,
+                           algorithmic_gflop_per_step=d["work"] / steps / 1e9)
+            elif bound == "hbm":
+                ach = d["work"] / (d["ms"] * 1e-3) / 1e9
+                ent.update(achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                           algorithmic_mb_per_step=d["work"] / steps / 1e6)
+            else:
+                ent.update(achieved=None, peak=None, unit=None, frac=None, note="latency / VALU bound, LDS-resident: no roofline claim")
+            out.append(ent)
+        return out, by
 
 
 def cpu_baseline(cfg, sd):
-    """The oracle timed on the host cores: 1 pair, full forward, fp32 (bounded sample)."""
+    """The oracle timed on the host cores: 1 pair, full forward, fp32; one warm-up,
+    then the median of 3 runs, per stage (encoder / heads / matcher / solver) and in total."""
+    import torch
     from mickey_amd import synthetic as syn
     from oracle import mickey_oracle as O
     cores = min(os.cpu_count() or 1, 32)   # torch-CPU does not scale past ~32 threads on these ops (256 -> 10x slower)
     torch.set_num_threads(cores)
-    data = syn.synthetic_batch(B=1, H=H, W=W, seed=1234)
-    t0 = time.time()
-    with torch.no_grad():
-        O.mickey_forward(sd, cfg, data)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    pre = "compute_matches.extractor."
+    f = cfg["MICKEY"]["DINOV2"]["DOWN_FACTOR"]
+
+    def one(timed):
+        data = syn.synthetic_batch(B=1, H=H, W=W, seed=1234)
+        t = {}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            feats = []
+            for key in ("image0", "image1"):
+                img = data[key][:, :, : f * (H // f), : f * (W // f)]
+                tok = O.vit_forward_features(sd, pre + "dinov2_vitl14.", img, 16)
+                feats.append(tok.permute(0, 2, 1).reshape(1, tok.shape[-1], H // f, W // f).float())
+            t1 = time.perf_counter()
+            per = [O.extractor_heads(sd, cfg, ft, pre) for ft in feats]
+            t2 = time.perf_counter()
+            out = {}
+            for i, (kp, dp, sc, ds) in enumerate(per):
+                kp = O.abs_keypoints(kp, f)
+                n = kp.shape[2] * kp.shape[3]
+                out["kps%d" % i], out["depth_kp%d" % i] = kp.reshape(1, 2, n), dp.reshape(1, 1, n)
+                out["scr%d" % i], out["dsc%d" % i] = sc.reshape(1, 1, n), ds.reshape(1, ds.shape[1], n)
+            dust = sd.get("compute_matches.matcher.matching_mat.dustbin_score")
+            out["scores"] = O.dual_softmax(out["dsc0"], out["dsc1"], dust, cfg["FEATURE_MATCHER"]["DUAL_SOFTMAX"]["TEMPERATURE"])
+            out["final_scores"] = out["scores"] * torch.matmul(out["scr0"].transpose(2, 1).contiguous(), out["scr1"])
+            t3 = time.perf_counter()
+            data.update(out)
+            O.estimate_pose(data, cfg)
+            t4 = time.perf_counter()
+        t.update(encoder=t1 - t0, heads=t2 - t1, matcher=t3 - t2, solver=t4 - t3, total=t4 - t0)
+        return t
+
+    one(False)   # warm-up (thread pools, allocator, first-touch of the weights)
+    runs = [one(True) for _ in range(3)]
+    med = {k: sorted(r[k] for r in runs)[1] for k in runs[0]}
+    return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "kind": "port",
+            "protocol": "1 warm-up + median of 3", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
             "sample": "1 pair 540x720, full forward (ViT-L fp32 + heads + dual-softmax + 20x100 RANSAC), torch-CPU "
-                      "oracle, %.1f s" % dt}
+                      "oracle, median %.2f s per pair" % med["total"]}
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Re-execute this script as n ranks (one per GPU) under torch.distributed.run on 127.0.0.1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -101,21 +222,158 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--gemm-tile", type=int, default=0, help="mk_gemm_set_tile mode (0 = automatic)")
-    ap.add_argument("--attn-mode", type=int, default=0, help="mk_attn_set_mode mode (0 = default)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short fp16 run reported under 'alt'")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="also report the PCIe-inclusive rate: uint8 frames from pinned host memory through the input pipeline")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
+    ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="hipGraph replay of the forward (auto: batches of <= 4 pairs, where launches dominate)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend ('nccl' is RCCL on ROCm)")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST HOOK (tests/test_bench_cpu.py): CPU tensors and a trivial stand-in model, so that the launcher, "
+                         "sharding, gather and timing logic of --gpus N can be exercised under gloo without a GPU; "
+                         "the printed line is marked \"stub\": true and is not a measurement")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run (any world size)
+
+def resolve_world(args, env, device_count):
+    """-> (mode, world) with mode in {'single', 'spawn', 'rank'}; raises SystemExit with a clear message when the
+    request cannot be honoured.  Pure function of its inputs (unit-tested on CPU)."""
+    under_launcher = "RANK" in env and "WORLD_SIZE" in env
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if under_launcher:
+        world = int(env["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: they must agree" % (world, args.gpus))
+        if device_count < world:
+            raise SystemExit("bench.py: %d ranks requested but only %d GPU(s) visible on this node" % (world, device_count))
+        return "rank", world
+    if args.gpus == 1:
+        if device_count < 1:
+            raise SystemExit("bench.py: no GPU visible")
+        return "single", 1
+    if device_count < args.gpus:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) visible on this node" % (args.gpus, device_count))
+    return "spawn", args.gpus
+
+
+class _StubModel:
+    """--stub only: pose = deterministic function of the pair's image mean (no GPU, no kernels)."""
+
+    _graphs = {}
+
+    def __call__(self, data):
+        import torch
+        B = data["image0"].shape[0]
+        m = data["image0"].reshape(B, -1).mean(1)
+        data["R"] = torch.eye(3).repeat(B, 1, 1) * m.view(B, 1, 1)
+        data["t"] = torch.stack([m, 2 * m, 3 * m], 1).view(B, 1, 3)
+        data["inliers"] = (10 * m).view(B, 1)
+        return data["R"], data["t"]
+
+
+def measure(model, data0, args, use_dist, world, gatherer, prof=None):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = data0["image0"].is_cuda
+
+    class _Sync:   # torch.cuda.synchronize on the GPU; nothing to wait for on CPU tensors (--stub)
+        @staticmethod
+        def synchronize():
+            if on_gpu:
+                torch.cuda.synchronize()
+
+    def step():
+        data = dict(data0)
+        R, t = model(data)
+        if gatherer is not None:
+            data["_gather"] = gatherer.submit(R, t, data["inliers"])   # side stream; the main stream runs on
+        return data
+
+    last = None
+    for _ in range(args.warmup):
+        last = step()
+        if gatherer is not None:
+            gatherer.wait(last["_gather"])
+    _Sync.synchronize()
+    if use_dist:
+        dist.barrier()
+    _Sync.synchronize()
+    if prof is not None:
+        prof.on = True
+    t0 = time.perf_counter()
+    pending = []
+    for _ in range(args.steps):
+        last = step()
+        if gatherer is not None:
+            pending.append(last["_gather"])
+    poses = None
+    for h in pending:   # results are only needed here: every gather has had a whole forward to complete
+        poses = gatherer.wait(h)
+    _Sync.synchronize()
+    if use_dist:
+        dist.barrier()
+    _Sync.synchronize()
+    dt = time.perf_counter() - t0
+    if prof is not None:
+        prof.on = False
+    if use_dist:
+        tt = torch.tensor([dt], device=data0["image0"].device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, last, poses
+
+
+def main_stub(args, rank, world, use_dist):
+    """--stub: the same launcher / sharding / gather / timing code path on CPU tensors with a stand-in model."""
+    import torch
+    import torch.distributed as dist
+    from mickey_amd import distributed as D
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo", rank=rank, world_size=world)
+        world = dist.get_world_size()
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + 2 * rank)
+    data0 = {"image0": torch.rand((B, 3, 8, 8), generator=g), "image1": torch.rand((B, 3, 8, 8), generator=g)}
+    gatherer = D.PoseGatherer(None) if use_dist else None
+    dt, last, poses = measure(_StubModel(), data0, args, use_dist, world, gatherer, None)
+    if use_dist:
+        assert poses is not None and poses[0].shape[0] == world * B, "gathered poses do not cover the global batch"
+        # every rank's own poses sit at its slot of the gathered batch
+        assert torch.equal(poses[0][rank * B:(rank + 1) * B], last["R"])
+    if rank == 0:
+        print(json.dumps({"metric": "image pairs/sec (540x720)", "stub": True, "value": world * B * args.steps / dt,
+                          "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
+                          "config": {"pairs_per_gpu": B, "global_batch": world * B}}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch
+    mode, world = resolve_world(args, os.environ, args.gpus if args.stub else torch.cuda.device_count())
+    if mode == "spawn":
+        sys.exit(spawn_ranks(world, sys.argv[1:] if argv is None else list(argv)))
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = mode == "rank"
+    if args.stub:
+        return main_stub(args, rank, world, use_dist)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()   # what RCCL actually saw
 
     from mickey_amd import distributed as D
     from mickey_amd import ops, synthetic as syn
@@ -124,70 +382,60 @@ def main():
 
     ops.gemm_set_tile(args.gemm_tile)
     ops.attn_set_mode(args.attn_mode)
-    cfg = default_cfg()
-    cfg["AMD"]["ENCODER_DTYPE"] = args.dtype
-    cfg["AMD"]["SEED"] = rank
-    cfg["AMD"]["GRAPH"] = {"auto": "auto", "on": True, "off": False}[args.graph]
-    sd = syn.mickey_state_dict(cfg, seed=0)
-    model = MickeyRelativePose(cfg)
-    model.load_state_dict(sd)
-    model = model.to(dev)
+
+    def make_model(dtype):
+        cfg = default_cfg()
+        cfg["AMD"]["ENCODER_DTYPE"] = dtype
+        cfg["AMD"]["SEED"] = rank
+        cfg["AMD"]["GRAPH"] = {"auto": "auto", "on": True, "off": False}[args.graph]
+        sd = syn.mickey_state_dict(cfg, seed=0)
+        m = MickeyRelativePose(cfg)
+        m.load_state_dict(sd)
+        return m.to(dev), cfg, sd
+
+    model, cfg, sd = make_model(args.dtype)
     B = args.batch
     batch = syn.synthetic_batch(B=B, H=H, W=W, seed=1234 + 2 * rank)
     data0 = {k: v.to(dev) for k, v in batch.items()}
-    prof = GemmProfiler()
+    prof = None
     if not args.no_kernel_events:
+        prof = StageProfiler()
         prof.wrap(ops)
+    gatherer = D.PoseGatherer(dev) if use_dist else None
 
-    def step():
-        data = dict(data0)
-        R, t = model(data)
-        if use_dist:
-            data["poses_all"] = D.gather_poses(R, t, data["inliers"])   # the one collective: [B_local,13] -> [world*B_local,13]
-        return data
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    prof.on = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof.on = False
+    dt, last, poses = measure(model, data0, args, use_dist, world, gatherer, prof)
     graphed = len(model._graphs) > 0
-    if graphed and not args.no_kernel_events:
-        # a replayed graph bypasses the Python-level launch wrappers: time the GEMM launches of ONE extra eager step
+    ev_steps = args.steps
+    if graphed and prof is not None:
+        # a replayed graph bypasses the Python-level launch wrappers: time the launches of ONE extra eager step
         model.graph_mode = False
         prof.on = True
-        step()
+        model(dict(data0))
         torch.cuda.synchronize()
         prof.on = False
+        ev_steps = 1
     if use_dist:
-        assert last["poses_all"][0].shape[0] == world * B
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        assert poses is not None and poses[0].shape[0] == world * B, "gathered poses do not cover the global batch"
     ok = bool(torch.isfinite(last["R"]).all())
 
+    out = None
     if rank == 0:
-        g = prof.summary()
         roof = None
-        if g:
-            roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2)" % args.dtype,
-                    "achieved": g["tflops"], "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": g["tflops"] / PEAK_MFMA_TF,
-                    "traffic": pmc_traffic_bytes(B), "traffic_unit": "bytes/launch (L2-miss side, PMC)",
-                    "algorithmic_bytes_per_launch": 1.403e9 * B / 32.0, "launches": g["launches"], "avg_launch_ms": g["avg_launch_ms"],
-                    "avg_launch_gflop": g["avg_launch_gflop"]}
-            if graphed:
-                roof["note"] = "forward replayed as a hipGraph in the timed region; kernel events from one extra eager step"
+        if prof is not None and prof.records:
+            stages, by = prof.summary(ev_steps)
+            g = by.get("encoder_gemm")
+            if g:
+                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2, patch embed)" % args.dtype,
+                        "achieved": tf, "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TF,
+                        "traffic": pmc_traffic_bytes(B), "traffic_unit": "bytes/launch (L2-miss side, PMC)",
+                        "traffic_source": TRAFFIC_SOURCE + " (committed rocprofv3 --pmc passes of this workload; a constant, "
+                                          "not measured in this run)",
+                        "algorithmic_bytes_per_launch": 1.403e9 * B / 32.0, "launches": g["launches"],
+                        "avg_launch_ms": g["ms"] / g["launches"], "avg_launch_gflop": g["work"] / g["launches"] / 1e9,
+                        "stages": stages}
+                if graphed:
+                    roof["note"] = "forward replayed as a hipGraph in the timed region; kernel events from one extra eager step"
         out = {
             "metric": "image pairs/sec (540x720)", "value": world * B * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -195,11 +443,26 @@ def main():
             "config": {"workload": "MickeyRelativePose.forward, ViT-L/14 + 4 heads + dual-softmax + 20x100-hypothesis "
                                    "Procrustes RANSAC, %d pairs/GPU of 540x720 (W x H), random-init weights" % B,
                        "pairs_per_gpu": B, "global_batch": world * B, "image_hw": [H, W], "keypoints": 1938,
-                       "hypotheses": 2000, "parallelism": "pairs sharded over %d GPU(s), 1 all-gather of poses" % world,
+                       "hypotheses": 2000, "parallelism": "pairs sharded over %d GPU(s), 1 all-gather of poses "
+                                                          "(side stream)" % world,
                        "hip_graph": graphed},
             "roofline": roof,
             "finite_output": ok,
         }
+    if not args.no_alt and args.dtype == "bf16" and not use_dist:
+        del model
+        torch.cuda.empty_cache()
+        m16, _, _ = make_model("fp16")
+        a2 = argparse.Namespace(**vars(args))
+        a2.steps, a2.warmup = max(2, min(args.steps, 3)), 1
+        dt16, _, _ = measure(m16, data0, a2, False, 1, None, None)
+        out["alt"] = {"dtype": "fp16", "value": B * a2.steps / dt16, "unit": "pairs/s", "steps": a2.steps,
+                      "note": "fp16 operands are the reference's own low-precision mode (MICKEY.DINOV2.FLOAT16)"}
+        del m16
+    if rank == 0 and args.include_h2d and not use_dist:
+        from mickey_amd import input_pipeline as ip
+        out["pcie_inclusive"] = ip.bench_h2d(make_model(args.dtype)[0], B, H, W, steps=max(2, min(args.steps, 3)))
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         else:

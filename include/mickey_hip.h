@@ -12,9 +12,12 @@
  *   - every function returns MK_OK (0) or an MK_ERR_* code; mk_last_error() gives the text.
  *   - functions only enqueue work on `stream`: no allocation, no synchronisation, no host<->device
  *     copies.  Scratch memory is passed in by the caller (sizes documented per function).
- *   - re-entrant: no mutable globals besides the thread-local error string.
+ *   - re-entrant: no mutable globals besides the thread-local error string (the process-wide schedule
+ *     selectors for benchmarks / tests live in mickey_hip_dev.h, not in this ABI).
  *   - "lp" (low precision) buffers hold bf16 or fp16 according to `dtype` (MK_BF16 / MK_F16);
- *     accumulation is always fp32.
+ *     accumulation is always fp32.  dtype MK_F32 is the exact parity mode: "lp" buffers hold fp32 and
+ *     every contraction runs on the fp32-input MFMA (the reference's FLOAT16: False path and its
+ *     always-fp32 heads, mickey_extractor.py:31-35,49-56); about 16x slower, same entry points.
  */
 #ifndef MICKEY_HIP_H
 #define MICKEY_HIP_H
@@ -26,7 +29,7 @@ extern "C" {
 typedef void* mk_stream_t; /* hipStream_t */
 
 enum { MK_OK = 0, MK_ERR_INVALID_ARGUMENT = 1, MK_ERR_LAUNCH = 2 };
-enum { MK_BF16 = 0, MK_F16 = 1 };
+enum { MK_BF16 = 0, MK_F16 = 1, MK_F32 = 2 };
 enum { MK_ACT_NONE = 0, MK_ACT_RELU = 1, MK_ACT_GELU = 2 };
 /* internal epilogue selectors of the GEMM kernel (exposed for tests/tools only) */
 enum { MK_EPI_STORE = 0, MK_EPI_LS_RESIDUAL = 1, MK_EPI_QKV = 2, MK_EPI_PATCH = 3 };
@@ -43,19 +46,6 @@ const char* mk_last_error(void);
  * (att_layers/transformer_utils.py:55-57,60,64).  K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0. */
 int mk_gemm(const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldc, int M, int N, int K,
             int act, int out_is_f32, int dtype, mk_stream_t stream);
-
-/* Schedule selection of the GEMM/conv kernel: 0 = automatic (128x128 two-stage for small problems, the 256x256
- * full-line ping-pong schedule for large ones), 1 = force 128x128, 2 = force the 256x256 persistent K-stream kernel,
- * 3 = force the K=32 ping-pong ring, 4 = automatic with schedule 2 for large problems, 5/7/8/9 = full-line
- * ping-pong variants (persistent / banded tile order on or off); 10..21 = timing ablations (wrong results; only when
- * built with -DMK_GEMM_ABLATIONS).
- * Process-wide; for benchmarks and tests. */
-int mk_gemm_set_tile(int mode);
-
-/* Profiling hook (dev): while `buf` is non-null, bf16 dense launches of the full-line ping-pong schedule write 6
- * uint64 per (tile, wave-row): entry / first-stage-landed / K-loop-done / epilogue-issued on the 100 MHz wall clock,
- * HW_ID, XCC_ID.  buf must hold tiles*2*6 values.  Pass null to switch off. */
-int mk_gemm_debug_timeline(void* buf);
 
 /* `groups` independent GEMMs of identical shape in one launch (element strides per group; a stride
  * of 0 shares the operand).  Used to run the four heads side by side. */
@@ -107,12 +97,6 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
  * out lp [nimg*ntok, ldo] with column head*64 + d. */
 int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, int ldo, int nimg, int heads, int ntok,
                       int ntok_pad, int dtype, mk_stream_t stream);
-
-/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave,
- * 2 = 64 queries/wave, 3 = software-pipelined (QK^T of tile t+1 overlaps the softmax of tile t), 4 = VALU-lean (max
- * folded into the MFMA accumulator init, row sums on the matrix pipe), 5 = VALU-lean with 8 waves.  Process-wide; for
- * benchmarks and tests. */
-int mk_attn_set_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Heads (reference lib/models/MicKey/modules/mickey_extractor.py:67-251)

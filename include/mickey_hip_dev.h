@@ -1,0 +1,28 @@
+/* mickey_hip_dev.h -- development knobs of libmickey_hip.so (benchmarks, tests, A/B tools).
+ *
+ * NOT part of the drop-in ABI (include/mickey_hip.h): these set PROCESS-WIDE state that selects between kernel
+ * schedules computing the same result.  The product path never calls them.
+ */
+#ifndef MICKEY_HIP_DEV_H
+#define MICKEY_HIP_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Schedule of the GEMM / implicit-GEMM conv kernel: 0 = automatic (128x128 tiles for small problems, the default
+ * 256x256 schedule for large ones), 1 = force 128x128 (4 waves, 2 workgroups per CU), 7 = force the 8-wave ping-pong
+ * 256x256 schedule (two waves per SIMD), 10 = force the one-wave-per-SIMD 256x256 schedule (4 waves, 128x128 per wave);
+ * 400 + b sets the band height b (in m-tiles) of the 256x256 tile order. */
+int mk_gemm_set_tile(int mode);
+
+/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave,
+ * 2 = 64 queries/wave, 3 = software-pipelined (QK^T of tile t+1 overlaps the softmax of tile t), 4 = VALU-lean (max
+ * folded into the MFMA accumulator init, row sums on the matrix pipe), 5 = VALU-lean with 8 waves.  Process-wide; for
+ * benchmarks and tests. */
+int mk_attn_set_mode(int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICKEY_HIP_DEV_H */

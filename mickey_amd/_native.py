@@ -10,7 +10,7 @@ import torch
 
 from . import build as _build
 
-MK_BF16, MK_F16 = 0, 1
+MK_BF16, MK_F16, MK_F32 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 _P, _I, _L, _F, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_ulonglong
@@ -21,8 +21,6 @@ SIGNATURES = {
     "mk_version": ("i", ""),
     "mk_last_error": ("s", ""),
     "mk_gemm": ("i", "pipippiiiiiiip"),
-    "mk_gemm_set_tile": ("i", "i"),
-    "mk_gemm_debug_timeline": ("i", "p"),
     "mk_gemm_grouped": ("i", "pilpilplpiliiiiiiip"),
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
     "mk_gemm_qkv": ("i", "pipippppiiiifip"),
@@ -30,7 +28,6 @@ SIGNATURES = {
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
     "mk_layernorm": ("i", "pippfpiipiiiiiiip"),
-    "mk_attn_set_mode": ("i", "i"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_conv3x3": ("i", "pliplipilplppiliiiiiipip"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
@@ -50,6 +47,13 @@ SIGNATURES = {
     "mk_ransac_hypotheses": ("i", "pppppuupfppppiiip"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),
     "mk_pose_finalize": ("i", "ppppip"),
+}
+
+# development knobs (include/mickey_hip_dev.h): process-wide schedule selectors for benchmarks / tests, never called by
+# the product path
+DEV_SIGNATURES = {
+    "mk_gemm_set_tile": ("i", "i"),
+    "mk_attn_set_mode": ("i", "i"),
 }
 
 _lib = None
@@ -74,7 +78,7 @@ def load():
         raise MickeyHipError("libmickey_hip.so not found at %s -- build it with `python -m mickey_amd.build` "
                              "(mickey_amd has no CPU/ATen fallback)" % path)
     lib = ctypes.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEV_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError:
@@ -112,6 +116,8 @@ def dtype_code(dt):
         return MK_BF16
     if dt == torch.float16:
         return MK_F16
+    if dt == torch.float32:
+        return MK_F32   # the exact parity mode: "lp" buffers hold fp32, contractions on the fp32-input MFMA
     raise MickeyHipError("unsupported low-precision dtype %s" % dt)
 
 

@@ -18,6 +18,12 @@
 
 #include "mk_common.hpp"
 
+namespace mk {
+// exact-fp32 parity mode (mk_attention_f32.hip)
+void launch_attn_f32(const float* q, const float* k, const float* vt, float* out, int ldo, int nimg, int heads, int ntok,
+                     int ntok_pad, hipStream_t st);
+}
+
 namespace {
 using namespace mk;
 
@@ -562,6 +568,9 @@ extern "C" int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, v
     launch_attn<__bf16>(q, k, vt, out, ldo, nimg, heads, ntok, ntok_pad, (hipStream_t)stream);
   else if (dtype == MK_F16)
     launch_attn<_Float16>(q, k, vt, out, ldo, nimg, heads, ntok, ntok_pad, (hipStream_t)stream);
+  else if (dtype == MK_F32)
+    mk::launch_attn_f32((const float*)q, (const float*)k, (const float*)vt, (float*)out, ldo, nimg, heads, ntok, ntok_pad,
+                        (hipStream_t)stream);
   else
     MK_CHECK_ARG(false, "mk_flash_attn_fwd: bad dtype");
   MK_CHECK_LAUNCH();

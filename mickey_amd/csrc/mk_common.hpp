@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 
 #define MK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -57,6 +58,13 @@ template <> struct Lp<_Float16> {
   static __device__ __forceinline__ f32x16 mma32(V8 a, V8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+};
+
+// MK_F32: the exact-fp32 parity mode -- "low precision" buffers hold fp32 and contractions run on the fp32-input MFMA
+// (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma chain, 1/16 of the bf16 rate); only the vector types are needed here
+template <> struct Lp<float> {
+  using V8 = f32x8;
+  using V4 = f32x4;
 };
 
 // ---- wave64 reductions ---------------------------------------------------------------------------

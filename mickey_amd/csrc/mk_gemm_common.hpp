@@ -1,0 +1,481 @@
+// mickey_amd -- shared pieces of the 16-bit-operand MFMA GEMMs (mk_gemm.hip: dispatch + 128x128 kernel,
+// mk_gemm_pp64.hip: 8-wave ping-pong, mk_gemm_w4.hip: one wave per SIMD): parameters, LDS-DMA stager, epilogues.
+#pragma once
+#include "mk_common.hpp"
+
+namespace mk {
+namespace gemm {
+
+constexpr int BK = 64;   // K tile of the 16-bit kernels, in elements: LDS rows of 128 B
+// element-size generic forms (the fp32 parity kernel shares the stager and the epilogue): 16-byte chunk / 128-byte row
+template <typename T> constexpr int EPC = 16 / (int)sizeof(T);
+template <typename T> constexpr int KT = 128 / (int)sizeof(T);
+
+enum AMode { A_DENSE = 0, A_CONV3 = 1 };
+
+struct GemmParams {
+  // operands
+  const void* A;       // dense: [M, lda]; conv: NHWC activation of source 1
+  const void* A2;      // conv only: NHWC activation of source 2 (1x1 shortcut), may be null
+  const void* W;       // [N, ldw]
+  int M, N, K, lda, ldw;
+  long long strideA_g, strideA2_g, strideW_g;  // element strides per group (blockIdx.y)
+  // conv geometry
+  int H, Wd, C1, C2;   // image grid, channels of source 1 / source 2
+  const void* zero_page;
+  // epilogue
+  int epi;
+  int act;
+  const float* bias;   // [N]
+  const float* gamma;  // [N]
+  long long strideBias_g;
+  float* out_f32;
+  void* out_lp;
+  int ldc;
+  long long strideOut_g;
+  const void* resid_lp;  // identity residual, [M, ldc] low precision
+  // qkv split
+  void* q;
+  void* k;
+  void* vt;
+  int ntok, ntok_pad, heads;
+  float qscale;
+  // patch embed
+  const float* pos;
+  int npatch;
+};
+
+template <typename T>
+__device__ __forceinline__ T to_lp(float v) { return (T)v; }
+
+// swap bits 2 and 3 of a token index: the V^T image is stored key-permuted so that the 8 keys a lane
+// owns after the 32x32 S^T MFMA are one contiguous 16-B chunk (see mk_attention.hip)
+__device__ __forceinline__ int vperm(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
+
+// Per-lane LDS-DMA state of one workgroup tile.  Piece (wave*J + j) is 8 rows x 128 B = 1 KiB of the LDS image; this
+// lane feeds row +(lane>>3), 16-byte chunk lane&7 of it, fetching the XOR-swizzled source chunk.
+template <typename T, int AMODE, int NW, int AJ, int WJ>
+struct Stager {
+  const T* A;
+  const T* A2;
+  const T* wrow[WJ];
+  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: pixel index of the row
+  int ay[AJ], ax[AJ];
+  bool avalid[AJ];
+  int wave, srow, sp;
+
+  __device__ __forceinline__ void init(const GemmParams& p, int g, int m0, int n0, int wave_, int lane) {
+    wave = wave_;
+    srow = lane >> 3;
+    sp = lane & 7;
+    A = (const T*)p.A + (long long)g * p.strideA_g;
+    A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+    const T* W = (const T*)p.W + (long long)g * p.strideW_g;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int r = (wave * WJ + j) * 8 + srow;
+      int n = n0 + r;
+      n = n < p.N ? n : p.N - 1;
+      wrow[j] = W + (long long)n * p.ldw + swz8(r, sp) * EPC<T>;
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int r = (wave * AJ + j) * 8 + srow;
+      int m = m0 + r;
+      avalid[j] = m < p.M;
+      m = avalid[j] ? m : p.M - 1;
+      if (AMODE == A_DENSE) {
+        aoff[j] = (long long)m * p.lda + swz8(r, sp) * EPC<T>;
+        ay[j] = ax[j] = 0;
+      } else {
+        const int pix = m % (p.H * p.Wd);
+        ay[j] = pix / p.Wd;
+        ax[j] = pix % p.Wd;
+        aoff[j] = m;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void issue(const GemmParams& p, char* sA, char* sW, int kt) const {
+    const int k0 = kt * KT<T>;
+    if (AMODE == A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) glds16(A + aoff[j] + k0, sA + (wave * AJ + j) * 1024);
+    } else {
+      // wave-uniform: which source / tap does this K tile belong to
+      const int kc = 9 * p.C1;
+      const T* src;
+      int cs, c0, dy, dx;
+      if (k0 < kc) {
+        const int tap = k0 / p.C1;
+        c0 = k0 - tap * p.C1;
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+        src = A;
+        cs = p.C1;
+      } else {
+        c0 = k0 - kc;
+        dy = dx = 0;
+        src = A2;
+        cs = p.C2;
+      }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int r = (wave * AJ + j) * 8 + srow;
+        const int yy = ay[j] + dy, xx = ax[j] + dx;
+        const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+        const T* s = ok ? src + (aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(r, sp) * EPC<T> : (const T*)p.zero_page + sp * EPC<T>;
+        glds16(s, sA + (wave * AJ + j) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) glds16(wrow[j] + k0, sW + (wave * WJ + j) * 1024);
+  }
+};
+
+// ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
+// EPI / ACT / HAS_BIAS are compile-time inside the 32x unrolled store loop; epilogue() dispatches once per tile.
+template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
+                                              int g) {
+  using V4 = typename Lp<T>::V4;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const int nb = n0 + wn * 64 + fg * 4;
+  f32x4 bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nb + ni * 16;
+    bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int mi = 0; mi < WMF; ++mi) {
+    const int m = m0 + wm * (WMF * 16) + mi * 16 + fr;
+    if (m >= p.M) continue;
+    int img = 0, tok = 0;
+    if (EPI == MK_EPI_QKV) {
+      img = m / p.ntok;
+      tok = m - img * p.ntok;
+    } else if (EPI == MK_EPI_PATCH) {
+      img = m / p.npatch;
+      tok = m - img * p.npatch;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = nb + ni * 16;
+      if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
+      f32x4 v = acc[mi][ni];
+      if (HAS_BIAS) v += bv[ni];
+      if (EPI == MK_EPI_STORE) {
+        if (p.resid_lp) {
+          const V4 r = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+        if (ACT == MK_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ACT == MK_ACT_GELU) {
+          v = gelu_erf4(v);
+        }
+        if (p.out_f32) {
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = v;
+        } else {
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          *(V4*)((T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = o;
+        }
+      } else if (EPI == MK_EPI_LS_RESIDUAL) {
+        float* x = p.out_f32 + (long long)m * p.ldc + n;
+        const f32x4 gm = *(const f32x4*)(p.gamma + n);
+        f32x4 r = *(const f32x4*)x;
+        r += gm * v;
+        *(f32x4*)x = r;
+      } else if (EPI == MK_EPI_PATCH) {
+        const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+        *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = v + pe;
+      } else {  // MK_EPI_QKV
+        const int D = p.heads * 64;
+        const int which = n / D;
+        const int rem = n - which * D;
+        const int head = rem >> 6, d = rem & 63;
+        const long long hb = (long long)img * p.heads + head;
+        if (which == 2) {
+          T* dst = (T*)p.vt + (hb * 64 + d) * p.ntok_pad + vperm(tok);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
+        } else {
+          if (which == 0) v *= p.qscale;
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          T* base = (T*)(which == 0 ? p.q : p.k);
+          *(V4*)(base + (hb * p.ntok_pad + tok) * 64 + d) = o;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int WMF>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
+                                         int g) {
+  switch (p.epi) {   // wave-uniform, once per output tile
+    case MK_EPI_LS_RESIDUAL: epilogue_impl<T, WMF, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_QKV: epilogue_impl<T, WMF, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_PATCH: epilogue_impl<T, WMF, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
+    default:
+      if (!p.bias) {
+        if (p.act == MK_ACT_RELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, m0, n0, wm, wn, lane, g);
+        else epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, m0, n0, wm, wn, lane, g);
+      } else {
+        if (p.act == MK_ACT_RELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, m0, n0, wm, wn, lane, g);
+        else epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue of the full-line ping-pong kernel.  In the accumulator layout a lane owns 4 features of one
+// row, so a direct store instruction touches 16 rows x 32 B -- measured ~65 cycles per instruction and 4.4-7.2 us
+// per 256x256 tile (13-21 % of a K = 1024 tile).  After the K loop the 128-KiB ring is idle: each wave bounces its
+// 128x64 block through a private 16-KiB slice (wave-local, LDS is in-order per wave: no barrier) and then moves whole
+// rows: 16-bit outputs 16 B per lane = 8 full 128-byte lines per instruction, fp32 outputs (two 64-row halves) 4 x
+// 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
+// only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
+// XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
+template <typename T, int EPI, int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
+                                                  int wn, int lane, int g) {
+  using V4 = typename Lp<T>::V4;
+  using V8 = typename Lp<T>::V8;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
+  const int nw = n0 + wn * 64;        // first feature of this wave's block
+  const int mw = m0 + wm * 128;       // first row
+  // qkv split: (image, token) of row mw + r without a per-row integer division (~25 VALU incl. quarter-rate ops, 16 per
+  // lane before): one wave-uniform division; the wave's 128 rows cross at most one image boundary when ntok >= 128
+  int img0 = 0, tok0 = 0;
+  if (EPI == MK_EPI_QKV) {
+    img0 = mw / p.ntok;
+    tok0 = mw - img0 * p.ntok;
+  }
+  auto img_tok = [&](int r, int& img, int& tok) {
+    if (p.ntok >= 128) {
+      const int t = tok0 + r;
+      const bool wrap = t >= p.ntok;
+      img = img0 + (wrap ? 1 : 0);
+      tok = wrap ? t - p.ntok : t;
+    } else {
+      const int m = mw + r;
+      img = m / p.ntok;
+      tok = m - img * p.ntok;
+    }
+  };
+  f32x4 bv[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = nw + fg * 4 + ni * 16;
+    bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32);
+  if (lp_out) {
+    int which = 0, head = 0;
+    if (EPI == MK_EPI_QKV) {
+      const int D = p.heads * 64;
+      which = nw / D;
+      head = (nw - which * D) >> 6;
+      if (which == 2) {   // V^T, key-permuted: element stores straight from the accumulators
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = mw + mi * 16 + fr;
+          if (m >= p.M) continue;
+          int img, tok;
+          img_tok(mi * 16 + fr, img, tok);
+          const long long hb = (long long)img * p.heads + head;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni] + bv[ni];
+            T* dst = (T*)p.vt + (hb * 64 + ni * 16 + fg * 4) * p.ntok_pad + vperm(tok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
+          }
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int r = mi * 16 + fr;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 v = acc[mi][ni];
+        if (HAS_BIAS) v += bv[ni];
+        if (EPI == MK_EPI_QKV) {
+          if (which == 0) v *= p.qscale;
+        } else {
+          if (p.resid_lp) {
+            const int m = mw + r, n = nw + fg * 4 + ni * 16;
+            if (m < p.M && n < p.N) {
+              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+            }
+          }
+          if (ACT == MK_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (ACT == MK_ACT_GELU) {
+            v = gelu_erf4(v);
+          }
+        }
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+        const int c = ni * 2 + (fg >> 1);
+        *(V4*)(wl + r * 128 + ((c ^ (r & 7)) << 4) + (fg & 1) * 8) = o;
+      }
+    }
+    const int rr = lane >> 3, c = lane & 7;
+    const int n = nw + c * 8;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 8 + rr;
+      const int m = mw + r;
+      const V8 val = *(const V8*)(wl + r * 128 + ((c ^ (r & 7)) << 4));
+      if (m >= p.M || n >= p.N) continue;
+      T* dst;
+      if (EPI == MK_EPI_QKV) {
+        int img, tok;
+        img_tok(r, img, tok);
+        dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
+      } else {
+        dst = (T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n;
+      }
+      if (n + 8 <= p.N) {
+        *(V8*)dst = val;
+      } else {   // N % 8 == 4: the last chunk is half wide
+        V4 lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = val[e];
+        *(V4*)dst = lo;
+      }
+    }
+  } else {
+    const int rr = lane >> 4, c = lane & 15;
+    const int n = nw + c * 4;
+    f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == MK_EPI_LS_RESIDUAL && n < p.N) gm = *(const f32x4*)(p.gamma + n);
+    // read-modify-write of the residual stream: all 16 loads of a half are issued before anything waits on them (one
+    // HBM round trip per half instead of one per row group: measured 0.68 us per dependent load -> 22 us per tile);
+    // the second half's loads go out while the first half is still being stored
+    f32x4 xr[2][16];
+    auto preload = [&](int half) {
+      if (EPI != MK_EPI_LS_RESIDUAL) return;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = mw + half * 64 + it * 4 + rr;
+        xr[half][it] = (m < p.M && n < p.N) ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto stage = [&](int half) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int r = mi * 16 + fr;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4 v = acc[half * 4 + mi][ni];
+          if (HAS_BIAS) v += bv[ni];
+          if (EPI == MK_EPI_STORE) {
+            if (p.resid_lp) {
+              const int m = mw + half * 64 + r, nn = nw + fg * 4 + ni * 16;
+              if (m < p.M && nn < p.N) {
+                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + nn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+              }
+            }
+            if (ACT == MK_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (ACT == MK_ACT_GELU) {
+              v = gelu_erf4(v);
+            }
+          }
+          const int cw = ni * 4 + fg;
+          *(f32x4*)(wl + r * 256 + ((cw ^ (r & 15)) << 4)) = v;
+        }
+      }
+    };
+    auto drain = [&](int half) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 4 + rr;
+        const int m = mw + half * 64 + r;
+        const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
+        if (m >= p.M || n >= p.N) continue;
+        if (EPI == MK_EPI_LS_RESIDUAL) {
+          f32x4 x = xr[half][it];
+          x += gm * val;
+          *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+        } else if (EPI == MK_EPI_PATCH) {
+          const int img = m / p.npatch, tok = m - img * p.npatch;
+          const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+          *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = val + pe;
+        } else {
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
+        }
+      }
+    };
+    preload(0);
+    stage(0);
+    preload(1);
+    drain(0);
+    stage(1);
+    drain(1);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
+                                             int lane, int g) {
+  switch (p.epi) {   // wave-uniform, once per output tile
+    case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+    default:
+      if (!p.bias) {
+        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      } else {
+        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      }
+  }
+}
+
+// Tile order of the 256x256 kernels: bands of PP_GM m-tiles walked n-major (on top of the XCD remap), so the 32 tiles an
+// XCD works on at one time form an 8 x 4 block of the output (A and W panels shared in its L2).
+__device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_GM, int& tm, int& tn) {
+  const int band = id / (PP_GM * ntn);
+  const int rem = id - band * (PP_GM * ntn);
+  const int gm = min(PP_GM, ntm - band * PP_GM);
+  tm = band * PP_GM + rem % gm;
+  tn = rem / gm;
+}
+
+int num_cus();
+// schedule launchers (one translation unit each); amode = A_DENSE | A_CONV3, dtype = MK_BF16 | MK_F16
+int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
+int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)
+int launch_w4(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
+int launch_w4_variant(const GemmParams& p, int groups, hipStream_t st, int band_m, int dsch);   // dev (bf16 dense only)
+int launch_w4k32(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);   // needs K >= 192
+
+}  // namespace gemm
+}  // namespace mk

@@ -1,0 +1,232 @@
+// mickey_amd -- 8-wave full-line ping-pong GEMM schedule (256x256 tile, two waves per SIMD).
+#include <type_traits>
+
+#include "mk_gemm_common.hpp"
+
+namespace mk {
+namespace gemm {
+namespace {
+
+// Ping-pong with FULL-LINE LDS-DMA pieces: 256x256 tile, 8 waves (wave-row g = wave>>2), LDS stages of K = 64
+// (128-byte rows, the swz8 swizzle of the plain kernel), computed in two K = 32 sub-steps h.  A piece is 8 rows x
+// 128 B (8 full cache lines).  Only two 64-KiB stages fit, which is deep enough because the operand halves are released
+// at different times:
+//   * wave-row g loads AND reads only its own A half (rows 128g..128g+127); W is loaded and read by everyone;
+//   * slots (barrier at every boundary):  row g does  L(kt,h) [12 fragment reads] in slot 4kt+2h+g  and
+//     C(kt,h) [32 MFMAs from registers] in slot 4kt+2h+g+1;
+//   * A_g(kt+2) is issued in row g's C(kt,1) slot (its last reader, L(kt,1) of the same row, is one barrier behind) --
+//     BETWEEN the MFMAs of that slot (a piece issued between a wave's MFMAs costs ~12 cycles, four of them issued
+//     after the MFMAs ~240 cycles of the critical slot: tools/micro/r2_probe.hip);
+//     W(kt+1) is issued in row g's L(kt,0) slot (the last reader of W(kt-1), row 1 in slot 4kt-1, is behind);
+//   * every DMA has 3-5 slots to land; once per stage a counted vmcnt at the end of slot 4kt+3 (row 0: 4 newer DMAs
+//     may stay in flight; row 1: 0) precedes the barrier that opens stage kt+1.
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
+  using V8 = typename Lp<T>::V8;
+  constexpr int WMF = 8, BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;   // 64 KiB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = blockIdx.y;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int nk = p.K / BK;
+
+  const T* A = (const T*)p.A + (long long)g * p.strideA_g;
+  const T* A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+  const T* W = (const T*)p.W + (long long)g * p.strideW_g;
+  const int srow = lane >> 3, sp = lane & 7;
+  int tm, tn;
+  pp_tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, band_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  // this wave's 4 A pieces (own half) and 4 W pieces of a stage; piece = 8 rows x 128 B
+  // (32-bit element offsets: the launcher routes operands of 2^31 elements or more to the 128x128 kernel)
+  unsigned woff[4], aoff[4];
+  int ay[4], ax[4];
+  bool avalid[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rw = (wave * 4 + j) * 8 + srow;
+    int n = n0 + rw;
+    n = n < p.N ? n : p.N - 1;
+    woff[j] = (unsigned)n * (unsigned)p.ldw + swz8(rw, sp) * 8;
+    const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
+    int m = m0 + ra;
+    avalid[j] = m < p.M;
+    m = avalid[j] ? m : p.M - 1;
+    if (AMODE == A_DENSE) {
+      aoff[j] = (unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8;
+      ay[j] = ax[j] = 0;
+    } else {
+      const int pix = m % (p.H * p.Wd);
+      ay[j] = pix / p.Wd;
+      ax[j] = pix % p.Wd;
+      aoff[j] = m;
+    }
+  }
+  auto dma_w1 = [&](int s, int j) {
+    glds16(W + (woff[j] + (unsigned)(s * BK)), smem + (s & 1) * STAGE_BYTES + A_BYTES + (wave * 4 + j) * 1024);
+  };
+  auto dma_a1 = [&](int s, int j) {
+    char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
+    const int k0 = s * BK;
+    if (AMODE == A_DENSE) {
+      glds16(A + (aoff[j] + (unsigned)k0), dst);
+    } else {
+      const int kc = 9 * p.C1;
+      const T* src;
+      int cs, c0, dy, dx;
+      if (k0 < kc) {
+        const int tap = k0 / p.C1;
+        c0 = k0 - tap * p.C1;
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+        src = A;
+        cs = p.C1;
+      } else {
+        c0 = k0 - kc;
+        dy = dx = 0;
+        src = A2;
+        cs = p.C2;
+      }
+      const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
+      const int yy = ay[j] + dy, xx = ax[j] + dx;
+      const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+      const T* sp_ = ok ? src + ((long long)aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
+      glds16(sp_, dst);
+    }
+  };
+  auto dma_w = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_w1(s, j);
+  };
+  auto dma_a = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a1(s, j);
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  auto load_frags = [&](V8* wf, V8* xf, int par, int h) {
+    const char* sA = smem + par * STAGE_BYTES;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rw = wn * 64 + i * 16 + fr;
+      wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, h * 4 + fg) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WMF; ++i) {
+      const int rx = wm * 128 + i * 16 + fr;
+      xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, h * 4 + fg) * 16);
+    }
+  };
+  f32x4 acc[WMF][4];
+#pragma unroll
+  for (int i = 0; i < WMF; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s go out BETWEEN them (behind MFMA 3, 11, 19, 27), pinned
+  auto mfma32 = [&](const V8* wf, const V8* xf, auto dma, int s) {
+    constexpr bool DMA = decltype(dma)::value;
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int mi = q >> 2, ni = q & 3;
+      acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+      if (DMA && (q & 7) == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_a1(s, q >> 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  V8 wf[4], xf[WMF];
+  // one K = 64 stage of wave-row 0 / 1; NEXT1: stage kt+1 exists, NEXT2: stage kt+2 exists (compile time: the slots stay
+  // single basic blocks, so the DMA pieces can be pinned between the MFMAs)
+  auto stage0 = [&](int kt, auto next1, auto next2) {
+    bar();   // slot 4kt
+    load_frags(wf, xf, kt & 1, 0);
+    if constexpr (decltype(next1)::value) dma_w(kt + 1);
+    bar();                      // slot 4kt+1
+    mfma32(wf, xf, No{}, 0);
+    bar();                      // slot 4kt+2
+    load_frags(wf, xf, kt & 1, 1);
+    bar();                      // slot 4kt+3
+    mfma32(wf, xf, next2, kt + 2);
+    if constexpr (decltype(next2)::value)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto stage1 = [&](int kt, auto next1, auto next2) {
+    bar();                      // slot 4kt+1
+    load_frags(wf, xf, kt & 1, 0);
+    if constexpr (decltype(next1)::value) dma_w(kt + 1);
+    bar();                      // slot 4kt+2
+    mfma32(wf, xf, No{}, 0);
+    bar();                      // slot 4kt+3
+    load_frags(wf, xf, kt & 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
+    bar();                      // slot 4kt+4
+    mfma32(wf, xf, next2, kt + 2);
+  };
+
+  // prologue: stage 0 (own A half + W share) and the own A half of stage 1 (nk >= 2, see launch())
+  dma_a(0);
+  dma_w(0);
+  dma_a(1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (wm == 0) {
+    for (int kt = 0; kt < nk - 2; ++kt) stage0(kt, Yes{}, Yes{});
+    stage0(nk - 2, Yes{}, No{});
+    stage0(nk - 1, No{}, No{});
+    bar();   // row 1's last fragment reads are done, the LDS ring is free
+  } else {
+    bar();   // slot 0: this wave-row idles
+    for (int kt = 0; kt < nk - 2; ++kt) stage1(kt, Yes{}, Yes{});
+    stage1(nk - 2, Yes{}, No{});
+    stage1(nk - 1, No{}, No{});
+  }
+  epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g);
+}
+
+template <typename T, int AMODE>
+int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
+  constexpr int LDS = 2 * 512 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MK_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p, band_m);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+}  // namespace
+
+int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m) {
+  if (amode == A_DENSE)
+    return dtype == MK_BF16 ? launch_t<__bf16, A_DENSE>(p, groups, st, band_m) : launch_t<_Float16, A_DENSE>(p, groups, st, band_m);
+  return dtype == MK_BF16 ? launch_t<__bf16, A_CONV3>(p, groups, st, band_m) : launch_t<_Float16, A_CONV3>(p, groups, st, band_m);
+}
+
+}  // namespace gemm
+}  // namespace mk

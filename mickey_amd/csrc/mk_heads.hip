@@ -236,9 +236,12 @@ int mk_posenc_add(const void* x, const float* pe, float* xs, void* cat, int ld_c
   if (dtype == MK_BF16)
     hipLaunchKernelGGL(posenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, pe, xs,
                        (__bf16*)cat, ld_cat, rows, npix, C, total4);
-  else
+  else if (dtype == MK_F16)
     hipLaunchKernelGGL(posenc_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, pe, xs,
                        (_Float16*)cat, ld_cat, rows, npix, C, total4);
+  else
+    hipLaunchKernelGGL(posenc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, pe, xs,
+                       (float*)cat, ld_cat, rows, npix, C, total4);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -271,9 +274,11 @@ int mk_linattn_apply(const float* qkv, const float* kv, void* out, int ldo, int 
   if (dtype == MK_BF16)
     hipLaunchKernelGGL(linattn_apply_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (__bf16*)out, ldo, L,
                        C);
-  else
+  else if (dtype == MK_F16)
     hipLaunchKernelGGL(linattn_apply_kernel<_Float16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (_Float16*)out,
                        ldo, L, C);
+  else
+    hipLaunchKernelGGL(linattn_apply_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (float*)out, ldo, L, C);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

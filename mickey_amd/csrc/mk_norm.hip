@@ -174,8 +174,10 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                      out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows)
   if (dtype == MK_BF16) {
     if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
-  } else {
+  } else if (dtype == MK_F16) {
     if (D <= 1024) MK_LN(_Float16, 4); else MK_LN(_Float16, LN_MAXV);
+  } else {
+    if (D <= 1024) MK_LN(float, 4); else MK_LN(float, LN_MAXV);
   }
 #undef MK_LN
   MK_CHECK_LAUNCH();
@@ -192,9 +194,12 @@ int mk_im2col_patch14(const float* img, long long stride_img, long long stride_c
   if (dtype == MK_BF16)
     hipLaunchKernelGGL(im2col14_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, stride_img, stride_ch,
                        stride_row, nimg, gh, gw, (__bf16*)out, ldo);
-  else
+  else if (dtype == MK_F16)
     hipLaunchKernelGGL(im2col14_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, stride_img,
                        stride_ch, stride_row, nimg, gh, gw, (_Float16*)out, ldo);
+  else
+    hipLaunchKernelGGL(im2col14_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, stride_img,
+                       stride_ch, stride_row, nimg, gh, gw, (float*)out, ldo);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -59,13 +59,60 @@ def gather_poses(R, t, conf, sizes=None):
     return unpack_poses(keep)
 
 
-def forward_sharded(model, data, return_local=False):
-    """Run model.forward on this rank's shard of `data` and all-gather the poses."""
+class PoseGatherer:
+    """The one collective of the path, kept off the critical path: the all-gather of the packed poses
+    is issued on a SIDE stream that waits only for the kernels that produced R, t, conf; the main stream goes on with
+    the next batch and the result is waited for just before it is read.  On CPU tensors (gloo tests) it is synchronous."""
+
+    def __init__(self, device=None):
+        self.stream = torch.cuda.Stream(device) if device is not None and torch.device(device).type == "cuda" else None
+
+    def submit(self, R, t, conf, sizes=None):
+        if self.stream is None or not R.is_cuda:
+            return (None, gather_poses(R, t, conf, sizes))
+        packed = pack_poses(R, t, conf)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(R.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            out = gather_poses(*unpack_poses(packed), sizes=sizes)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        packed.record_stream(self.stream)
+        return (done, out)
+
+    def wait(self, handle):
+        done, out = handle
+        if done is not None:
+            torch.cuda.current_stream(out[0].device).wait_event(done)
+        return out
+
+
+def _empty_poses(device):
+    return (torch.zeros((0, 3, 3), device=device), torch.zeros((0, 1, 3), device=device), torch.zeros((0, 1), device=device))
+
+
+def forward_sharded(model, data, return_local=False, gatherer=None):
+    """Run model.forward on this rank's shard of `data` and all-gather the poses.  A rank whose shard is empty (global
+    batch smaller than the world size, e.g. the ragged last batch of an evaluation) skips the model call but still
+    takes part in the collective.  With a PoseGatherer the collective runs on its side stream."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     B = data["image0"].shape[0]
     local = shard_batch(data, rank, world)
-    R, t = model(local)
     sizes = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
-    Rg, tg, cg = gather_poses(R, t, local["inliers"], sizes)
+    if sizes[rank] > 0:
+        R, t = model(local)
+        conf = local["inliers"]
+    else:
+        try:
+            dev = next(model.parameters()).device
+        except (StopIteration, AttributeError):
+            dev = data["image0"].device
+        R, t, conf = _empty_poses(dev)
+        local["R"], local["t"], local["inliers"] = R, t, conf
+    if gatherer is not None:
+        Rg, tg, cg = gatherer.wait(gatherer.submit(R, t, conf, sizes))
+    else:
+        Rg, tg, cg = gather_poses(R, t, conf, sizes)
     return (Rg, tg, cg, local) if return_local else (Rg, tg, cg)

@@ -7,6 +7,7 @@ effects on ``data``, ``on_load_checkpoint`` / ``load_state_dict`` with the refer
 All arithmetic of ``forward`` runs in libmickey_hip.so on the module's device; there is no CPU / ATen
 fallback (a CPU-resident module raises on forward).
 """
+import collections
 import copy
 import os
 
@@ -15,9 +16,23 @@ import torch.nn as nn
 
 from . import _native, pipeline, weights
 from .config import as_cfg
-from .synthetic import DINO_PREFIX
+from .synthetic import DINO_PREFIX, DUSTBIN_KEY, VIT_ARCH, expected_keys
 
-_LP = {"bf16": torch.bfloat16, "fp16": torch.float16, "bfloat16": torch.bfloat16, "float16": torch.float16}
+_LP = {"bf16": torch.bfloat16, "fp16": torch.float16, "bfloat16": torch.bfloat16, "float16": torch.float16,
+       "fp32": torch.float32, "float32": torch.float32}
+# hub file the reference's extractor downloads in its constructor (reference mickey_extractor.py:14-17)
+DINOV2_URL = "https://dl.fbaipublicfiles.com/dinov2/dinov2_vitl14/dinov2_vitl14_pretrain.pth"
+
+
+def resolve_encoder_dtype(cfg):
+    """AMD.ENCODER_DTYPE: 'bf16' | 'fp16' | 'fp32', or 'auto' = follow the reference's own precision switch
+    MICKEY.DINOV2.FLOAT16 (reference mickey_extractor.py:31-35): True -> fp16 operands, False -> the exact-fp32 path."""
+    v = str(cfg["AMD"].get("ENCODER_DTYPE", "auto")).lower()
+    if v == "auto":
+        v = "fp16" if bool(cfg["MICKEY"]["DINOV2"].get("FLOAT16", True)) else "fp32"
+    if v not in _LP:
+        raise ValueError("AMD.ENCODER_DTYPE must be auto | bf16 | fp16 | fp32, got %r" % v)
+    return _LP[v]
 
 
 class _SolverView:
@@ -39,11 +54,17 @@ class _MatcherView:
         self._owner = owner
 
     def get_matches_list(self, scores, min_conf=0.0):
-        """Mutual nearest neighbours, sorted by score: reference feature_matcher.py:19-46 (B = 1 there;
-        batched here, returns the B = 1 tensor for a batch of one, a list otherwise)."""
+        """Mutual nearest neighbours with exp(score) > min_conf, sorted by score: reference feature_matcher.py:19-46
+        (B = 1 there; batched here, returns the B = 1 tensor for a batch of one, a list otherwise)."""
         from . import ops
-        m, c = ops.mutual_nn(scores.contiguous())
-        outs = [m[b, : int(c[b])].long() for b in range(scores.shape[0])]
+        scores = scores.contiguous()
+        m, c = ops.mutual_nn(scores)
+        outs = []
+        for b in range(scores.shape[0]):
+            mb = m[b, : int(c[b])].long()
+            if min_conf > 0.0 and mb.numel():   # the kernel applies the reference's default threshold exp(s) > 0
+                mb = mb[scores[b, mb[:, 0], mb[:, 1]].exp() > min_conf]
+            outs.append(mb)
         return outs[0] if len(outs) == 1 else outs
 
 
@@ -60,13 +81,15 @@ class MickeyRelativePose(nn.Module):
         super().__init__()
         self.cfg = as_cfg(cfg)
         amd = self.cfg["AMD"]
-        self.lp_dtype = _LP[str(amd.get("ENCODER_DTYPE", "bf16")).lower()]
+        self.lp_dtype = resolve_encoder_dtype(self.cfg)
+        self.heads_fp32 = str(amd.get("HEADS_DTYPE", "same")).lower() in ("fp32", "float32")
         self.lean = bool(amd.get("LEAN", False))
         self.seed = int(amd.get("SEED", 0))
         # hipGraph replay of the whole forward for launch-bound batches: "auto" (<= GRAPH_MAX_IMAGES images), True, False
         self.graph_mode = amd.get("GRAPH", "auto")
         self.graph_max_images = int(amd.get("GRAPH_MAX_IMAGES", 8))
-        self._graphs = {}
+        self.graph_cache_size = int(amd.get("GRAPH_CACHE", 4))   # captured input signatures kept (LRU)
+        self._graphs = collections.OrderedDict()
         self._calls = 0
         self._ctr = None   # device-resident 2 * _calls: the Philox stream offset (read by the kernels, so a graph can advance it)
         # a single registered parameter carries the module's device (reference callers use
@@ -77,13 +100,18 @@ class MickeyRelativePose(nn.Module):
         self._ws = pipeline.Workspace()
         self.e2e_Procrustes = _SolverView(self.cfg)
         object.__setattr__(self, "compute_matches", _ComputeMatchesView(self))
+        # the frozen encoder weights: an explicit dict, a local file (AMD.DINOV2_WEIGHTS / $MICKEY_DINOV2_WEIGHTS), or --
+        # as the reference's extractor does in its constructor (mickey_extractor.py:14-17) -- the hub download; "none"
+        # defers to a state_dict that carries them (tests, synthetic weights)
         if dinov2_weights is None:
             path = amd.get("DINOV2_WEIGHTS") or os.environ.get("MICKEY_DINOV2_WEIGHTS")
-            if path:
+            if path and str(path).lower() != "none":
                 dinov2_weights = torch.load(path, map_location="cpu")
+        self._dino_injected = set()
         if dinov2_weights is not None:
             for k, v in dinov2_weights.items():
                 self._sd[DINO_PREFIX + k] = v.detach().cpu()
+                self._dino_injected.add(DINO_PREFIX + k)
         self.eval()
 
     # ---- checkpoint contract ---------------------------------------------------------------------
@@ -91,19 +119,68 @@ class MickeyRelativePose(nn.Module):
         return dict(self._sd)
 
     def load_state_dict(self, state_dict, strict=True):
-        self._sd = {k: v.detach().cpu() for k, v in state_dict.items() if torch.is_tensor(v)}
+        """nn.Module.load_state_dict semantics against the reference's key layout: with strict=True
+        missing / unexpected keys and shape mismatches raise; with strict=False they are returned.  Keys absent from
+        `state_dict` keep their current value (so DINOv2 weights injected at construction survive a MicKey checkpoint
+        that was saved without them, which is how the reference's checkpoints are written: model.py:291-298)."""
+        new = {k: v.detach().cpu() for k, v in state_dict.items() if torch.is_tensor(v)}
+        arch = str(self.cfg["AMD"].get("VIT", "vit_large"))
+        if any(k.endswith("cls_token") for k in new):   # take the width from the checkpoint when it says otherwise
+            D = [v.shape[-1] for k, v in new.items() if k.endswith("cls_token")][0]
+            arch = {v[0]: k for k, v in VIT_ARCH.items()}.get(D, arch)
+        expected = expected_keys(self.cfg, arch)
+        if arch != "vit_large" or any(DINO_PREFIX + "blocks." in k for k in new):   # depth follows the checkpoint
+            have = [int(k[len(DINO_PREFIX) + 7:].split(".")[0]) for k in new if k.startswith(DINO_PREFIX + "blocks.")]
+            if have:
+                depth = 1 + max(have)
+                expected = {k: s for k, s in expected.items()
+                            if not k.startswith(DINO_PREFIX + "blocks.") or int(k[len(DINO_PREFIX) + 7:].split(".")[0]) < depth}
+        if not any("dinov2" in k for k in new) and not any("dinov2" in k for k in self._sd):
+            self._fetch_dinov2()
+        merged = dict(self._sd)
+        merged.update(new)
+        missing = [k for k in expected if k not in merged]
+        unexpected = [k for k in new if k not in expected]
+        bad_shape = ["%s: %s, expected %s" % (k, tuple(merged[k].shape), expected[k]) for k in expected
+                     if k in merged and tuple(merged[k].shape) != expected[k] and merged[k].numel() != 1]
+        if strict and (missing or unexpected or bad_shape):
+            hint = ""
+            if any(k.startswith(DINO_PREFIX) for k in missing):
+                hint = ("\n(MicKey checkpoints are saved without the DINOv2 weights: pass dinov2_weights=, or set "
+                        "AMD.DINOV2_WEIGHTS / $MICKEY_DINOV2_WEIGHTS to dinov2_vitl14_pretrain.pth; the hub download the "
+                        "reference performs was %s)" % (getattr(self, "_hub_error", None) or "disabled (AMD.DINOV2_HUB: False)"))
+            raise RuntimeError("Error(s) in loading state_dict for MickeyRelativePose:\n\tMissing key(s): %s\n\tUnexpected "
+                               "key(s): %s\n\tsize mismatch: %s%s" % (missing[:8] + (["..."] if len(missing) > 8 else []),
+                                                                     unexpected[:8], bad_shape[:8], hint))
+        self._sd = merged
         self._dev_weights = None
-        if strict and not any(k.startswith(DINO_PREFIX) for k in self._sd):
-            raise RuntimeError("state_dict holds no DINOv2 weights (%s*): pass dinov2_weights= / AMD.DINOV2_WEIGHTS or "
-                               "call on_load_checkpoint first, as the reference's build_model does" % DINO_PREFIX)
-        return torch.nn.modules.module._IncompatibleKeys([], [])
+        self._graphs.clear()
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def _fetch_dinov2(self):
+        """The reference's extractor downloads dinov2_vitl14_pretrain.pth in its constructor (mickey_extractor.py:14-17);
+        here the download is deferred to the moment a checkpoint WITHOUT encoder weights is loaded and none were given
+        (dinov2_weights= / AMD.DINOV2_WEIGHTS / $MICKEY_DINOV2_WEIGHTS).  AMD.DINOV2_HUB: False forbids it."""
+        if not bool(self.cfg["AMD"].get("DINOV2_HUB", True)):
+            return False
+        try:
+            sd = torch.hub.load_state_dict_from_url(DINOV2_URL, map_location="cpu")
+        except Exception as e:   # no network, proxy, disk ...: reported by the strict load with the hint below
+            self._hub_error = "%s: %s" % (type(e).__name__, e)
+            return False
+        for k, v in sd.items():
+            self._sd[DINO_PREFIX + k] = v.detach().cpu()
+        return True
 
     def on_load_checkpoint(self, checkpoint):
         """MicKey checkpoints are saved without the frozen DINOv2 weights; re-inject them before
         load_state_dict (reference compute_pose.py:39-48)."""
+        sd = checkpoint["state_dict"]
+        if not any("dinov2" in k for k in self._sd) and not any("dinov2" in k for k in sd):
+            self._fetch_dinov2()
         for k, v in self._sd.items():
             if "dinov2" in k:
-                checkpoint["state_dict"][k] = v
+                sd[k] = v
 
     def is_eval_model(self, is_eval):  # reference compute_pose.py:50-60; inference-only here
         if not is_eval:
@@ -111,7 +188,7 @@ class MickeyRelativePose(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._dev_weights = None
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()
         self._ctr = None
         return super()._apply(fn, *a, **k)
 
@@ -127,7 +204,11 @@ class MickeyRelativePose(nn.Module):
         if self._dev_weights is None:
             if not self._sd:
                 raise RuntimeError("no weights loaded")
-            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype)
+            fm = self.cfg["FEATURE_MATCHER"]
+            if fm["TYPE"] == "DualSoftmax" and fm["DUAL_SOFTMAX"]["USE_DUSTBIN"] and DUSTBIN_KEY not in self._sd:
+                raise RuntimeError("FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN is set but the checkpoint has no %s (the "
+                                   "reference's strict load fails on this too)" % DUSTBIN_KEY)
+            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_fp32=self.heads_fp32)
         return self._dev_weights
 
     # ---- forward ---------------------------------------------------------------------------------
@@ -199,13 +280,15 @@ class MickeyRelativePose(nn.Module):
         Two modules with equal weights, seed and call count produce bit-identical poses."""
         if seed is not None:
             if int(seed) != self.seed:
-                self._graphs = {}   # the seed is a kernel argument baked into captured graphs
+                self._graphs.clear()   # the seed is a kernel argument baked into captured graphs
             self.seed = int(seed)
         self._calls = int(calls)
         if self._ctr is not None:
             self._ctr.fill_(2 * self._calls)
 
     _GRAPH_INPUTS = ("image0", "image1", "K_color0", "K_color1")
+    _LEAN_KEYS = ("R", "t", "inliers", "depth0_map", "depth1_map", "scr0", "scr1", "kps0", "kps1", "depth_kp0", "depth_kp1",
+                  "kps0_shape", "kps1_shape", "down_factor")
 
     def _wants_graph(self, data, return_inliers):
         mode = self.graph_mode
@@ -244,13 +327,20 @@ class MickeyRelativePose(nn.Module):
             self._calls = calls
             entry = (graph, static, gdata)
             self._graphs[key] = entry
+            while len(self._graphs) > max(1, self.graph_cache_size):   # each entry owns a private memory pool: bound it
+                self._graphs.popitem(last=False)
+        self._graphs.move_to_end(key)
         graph, static, gdata = entry
         for k in self._GRAPH_INPUTS:
             static[k].copy_(data[k], non_blocking=True)
         self._calls += 1
         graph.replay()
+        # everything the forward wrote is cloned out of the graph's pool (a later replay overwrites it); in LEAN mode only
+        # what the inference callers read (submission.py:40-45, demo_inference.py:120-123): poses, confidence, depth / score
+        # maps and keypoints -- not the three [B, n, n] score matrices and the descriptors
+        keep = self._LEAN_KEYS if self.lean else None
         for k, v in gdata.items():
-            if k not in self._GRAPH_INPUTS:
+            if k not in self._GRAPH_INPUTS and (keep is None or k in keep):
                 data[k] = v.clone() if torch.is_tensor(v) else copy.copy(v)
         return data["R"], data["t"]
 

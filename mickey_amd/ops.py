@@ -19,13 +19,8 @@ def _chk(t, dtype=None):
 
 
 def gemm_set_tile(mode):
-    """0 auto, 1 force the 128x128 tile, 2 force the 256x256 tile (tests / benchmarks)."""
+    """Dev knob (mickey_hip_dev.h): 0 auto, 1 force 128x128, 7 force the 8-wave ping-pong, 10 force one wave per SIMD."""
     call("mk_gemm_set_tile", int(mode))
-
-
-def gemm_debug_timeline(buf):
-    """Dev hook: int64 CUDA tensor of tiles*12 values receiving the per-tile timeline, or None to switch off."""
-    call("mk_gemm_debug_timeline", buf.data_ptr() if buf is not None else None)
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, out_f32=False, out=None, lda=None, K=None):
@@ -36,8 +31,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, out_f32=False, out=None, lda=None, K=Non
     K = min(lda, ldw) if K is None else K
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
-    call("mk_gemm", ptr(a), lda, ptr(w), ldw, ptr(bias), ptr(out), out.stride(0), M, N, K, act, int(out_f32),
-         dtype_code(a.dtype), stream())
+    call("mk_gemm", ptr(a), lda, ptr(w), ldw, ptr(bias), ptr(out), out.stride(0), M, N, K, act,
+         int(out.dtype == torch.float32), dtype_code(a.dtype), stream())
     return out
 
 
@@ -103,7 +98,7 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
 
 
 def attn_set_mode(mode):
-    """0 auto, 1 = 32 queries/wave, 2 = 64 queries/wave, 3 = software-pipelined (tests / benchmarks)."""
+    """Dev knob (mickey_hip_dev.h): attention kernel variant, 0 = automatic (tests / benchmarks)."""
     call("mk_attn_set_mode", int(mode))
 
 

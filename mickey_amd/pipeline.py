@@ -56,7 +56,7 @@ def encoder_forward(W, ws, img):
         ops.layernorm(x, blk.n2w, blk.n2b, 1e-6, out=y)
         ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
         ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
-    feat = ws.get("feat", (nimg * npatch, D), lp, dev)
+    feat = ws.get("feat", (nimg * npatch, D), getattr(W, "lp_heads", lp), dev)   # the heads' operand type
     ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1)
     return feat, gh, gw
 
@@ -64,7 +64,7 @@ def encoder_forward(W, ws, img):
 def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     """feat lp [nimg*n, D] -> scr [nimg,1,n], kps [nimg,2,n] (absolute pixels), depth [nimg,1,n],
     dsc [nimg,Cd,n], all fp32."""
-    dev, lp = feat.device, W.lp
+    dev, lp = feat.device, getattr(W, "lp_heads", W.lp)
     n = gh * gw
     M = nimg * n
     G = 4

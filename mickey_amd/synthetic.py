@@ -28,11 +28,18 @@ DINO_PREFIX = EXTRACTOR_PREFIX + "dinov2_vitl14."
 DUSTBIN_KEY = "compute_matches.matcher.matching_mat.dustbin_score"
 
 
+_SHAPES_ONLY = False   # expected_keys(): enumerate names / shapes without drawing 350 M random numbers
+
+
 def _randn(g, shape, std=1.0, mean=0.0):
+    if _SHAPES_ONLY:
+        return torch.empty(shape, device="meta")
     return torch.randn(shape, generator=g, dtype=torch.float32) * std + mean
 
 
 def _rand(g, shape, lo, hi):
+    if _SHAPES_ONLY:
+        return torch.empty(shape, device="meta")
     return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
 
 
@@ -114,7 +121,7 @@ def heads_state_dict(cfg, seed=0, prefix=EXTRACTOR_PREFIX):
         elif head == "det_offset":
             sd[hp + "xy_offset.weight"] = _randn(g, (2, last, 1, 1), 0.3)
         elif head == "depth_head":
-            sd[hp + "depth.weight"] = _randn(g, (1, last, 1, 1), 0.3).abs()
+            sd[hp + "depth.weight"] = _randn(g, (1, last, 1, 1), 0.3).abs() if not _SHAPES_ONLY else _randn(g, (1, last, 1, 1))
     return sd
 
 
@@ -129,6 +136,18 @@ def mickey_state_dict(cfg, seed=0, arch="vit_large", dustbin=1.0):
     else:
         sd[DUSTBIN_KEY] = torch.tensor(float(dustbin))
     return sd
+
+
+def expected_keys(cfg, arch="vit_large"):
+    """{key: shape} of a full MicKey state_dict for this config (the checkpoint contract of SURVEY.md 8(b)); used by
+    MickeyRelativePose.load_state_dict to report missing / unexpected keys the way nn.Module's strict load does."""
+    global _SHAPES_ONLY
+    _SHAPES_ONLY = True
+    try:
+        sd = mickey_state_dict(cfg, 0, arch)
+    finally:
+        _SHAPES_ONLY = False
+    return {k: tuple(v.shape) for k, v in sd.items()}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -85,12 +85,15 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16):
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False):
+    """heads_fp32: keep the four head stacks' operands in fp32 (the reference always runs them in fp32,
+    mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
     W = prepare_encoder(sd, device, lp_dtype)
     dev = device
+    W.lp_heads = torch.float32 if heads_fp32 else lp_dtype
 
     def lp(t):
-        return t.to(device=dev, dtype=lp_dtype).contiguous()
+        return t.to(device=dev, dtype=W.lp_heads).contiguous()
 
     def f32(t):
         return t.to(device=dev, dtype=torch.float32).contiguous()

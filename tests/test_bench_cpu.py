@@ -1,0 +1,78 @@
+"""bench.py's multi-GPU plumbing without a GPU: --gpus N must launch N ranks itself (torch.distributed.run on
+127.0.0.1), report the world size the process group saw, and refuse loudly what it cannot honour."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _args(gpus):
+    return argparse.Namespace(gpus=gpus)
+
+
+def test_resolve_world_rules():
+    assert bench.resolve_world(_args(1), {}, 1) == ("single", 1)
+    assert bench.resolve_world(_args(2), {}, 8) == ("spawn", 2)
+    assert bench.resolve_world(_args(8), {"RANK": "3", "WORLD_SIZE": "8"}, 8) == ("rank", 8)
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(_args(2), {}, 1)          # python bench.py --gpus 2 on a 1-GPU box
+    assert "only 1 GPU" in str(e.value)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(_args(1), {}, 0)
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(_args(4), {"RANK": "0", "WORLD_SIZE": "2"}, 8)   # torchrun of 2 ranks but --gpus 4
+    assert "must agree" in str(e.value)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(_args(8), {"RANK": "0", "WORLD_SIZE": "8"}, 4)
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--backend", "gloo", "--batch", "3", "--steps", "2",
+                        "--warmup", "1"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, timeout=300)
+    return r
+
+
+def test_gpus_2_spawns_two_ranks_under_gloo():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["stub"] is True and out["config"]["global_batch"] == 6 and out["steps"] == 2
+
+
+def test_gpus_1_is_single_process():
+    r = _run(["--gpus", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1
+
+
+def test_launcher_world_size_mismatch_fails_loudly():
+    r = _run(["--gpus", "4"], env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_real_bench_refuses_more_gpus_than_visible():
+    """Without --stub: this container has no GPU, so --gpus 2 must exit non-zero with a clear message (and must not
+    silently run one process, which is what round 1 did)."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2 GPUs visible here")
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)

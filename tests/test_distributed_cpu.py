@@ -72,6 +72,20 @@ def test_ragged_last_batch():
     _run(5)
 
 
+def test_fewer_pairs_than_ranks():
+    """B = 1 on 2 ranks: the rank with the empty shard skips the model call but still joins the collective (a
+    hang here is what submission_io.predict(sharded=True) would have hit on the last batch of an evaluation)."""
+    _run(1)
+
+
+def test_pose_gatherer_cpu_path_is_synchronous():
+    from mickey_amd import distributed as D
+    R, t, c = torch.eye(3).repeat(2, 1, 1), torch.ones(2, 1, 3), torch.full((2, 1), 7.0)
+    g = D.PoseGatherer(None)
+    Rg, tg, cg = g.wait(g.submit(R, t, c))
+    assert torch.equal(Rg, R) and torch.equal(tg, t) and torch.equal(cg, c)
+
+
 def test_shard_range_covers_everything():
     from mickey_amd.distributed import shard_range
     for n in (0, 1, 7, 8, 33):

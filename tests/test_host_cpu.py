@@ -26,6 +26,10 @@ def test_abi_exports_every_declared_symbol(nv):
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)   # declarations only
     declared = set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(nv.SIGNATURES), declared ^ set(nv.SIGNATURES)
+    # the dev knobs are declared in their own header, not in the drop-in ABI
+    dev = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mickey_hip_dev.h")).read(), flags=re.S)
+    assert set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", dev)) == set(nv.DEV_SIGNATURES)
+    assert not (declared & set(nv.DEV_SIGNATURES))
     assert nv.missing_symbols() == []
     assert nv.query("mk_version") >= 100
     # arity of every binding == arity of the C declaration

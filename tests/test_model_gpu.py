@@ -12,10 +12,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 KEYS = ("kps0", "kps1", "depth_kp0", "depth_kp1", "scr0", "scr1", "dsc0", "dsc1", "scores", "kp_scores", "final_scores")
-# rel-Frobenius bounds vs the fp32 reference for 16-bit operands (bf16 has 8 mantissa bits, fp16 11)
+# rel-Frobenius bounds vs the fp32 reference.  16-bit operands (bf16 has 8 mantissa bits, fp16 11): about 2x what is
+# measured on MI355X (bf16: kps 3e-5, depth 1.9e-3, scr 8e-3, dsc 6.9e-3, scores 8.3e-3, final_scores 1.2e-2; fp16: dsc 8e-4,
+# scores 7e-4 -- the reference's OWN fp16 mode sits at dsc 1.15e-3, scores 1.1e-3: tests/golden/noise_floor_fp16.npz), so a
+# real regression does not fit under them.  fp32 (the exact parity mode, fp32-input MFMA): 1e-4, SURVEY.md 8(c) row 1.
 TOL = {
-    torch.bfloat16: dict(kps=2e-4, depth=2e-2, scr=2e-2, dsc=2e-2, scores=4e-2, kp_scores=3e-2, final_scores=5e-2),
-    torch.float16: dict(kps=5e-5, depth=4e-3, scr=6e-3, dsc=5e-3, scores=1e-2, kp_scores=1e-2, final_scores=1.5e-2),
+    torch.bfloat16: dict(kps=8e-5, depth=4e-3, scr=1.6e-2, dsc=1.4e-2, scores=1.7e-2, kp_scores=3e-2, final_scores=2.5e-2),
+    torch.float16: dict(kps=5e-5, depth=1.5e-3, scr=3e-3, dsc=2e-3, scores=2e-3, kp_scores=6e-3, final_scores=4e-3),
+    torch.float32: dict(kps=1e-4, depth=1e-4, scr=1e-4, dsc=1e-4, scores=1e-4, kp_scores=1e-4, final_scores=1e-4),
 }
 
 
@@ -51,7 +55,7 @@ def test_vit_tiny_encoder_golden(golden):
     g = golden("vit_tiny")
     sd = syn.dinov2_state_dict("vit_tiny_test", seed=3)
     img = torch.rand((2, 3, 84, 126), generator=torch.Generator().manual_seed(11))
-    for dt, tol in ((torch.bfloat16, 1.5e-2), (torch.float16, 2.5e-3)):
+    for dt, tol in ((torch.bfloat16, 1.5e-2), (torch.float16, 2.5e-3), (torch.float32, 2e-5)):
         W = weights.prepare_encoder(sd, dev, dt, prefix="")
         feat, gh, gw = pipeline.encoder_forward(W, pipeline.Workspace(), img.to(dev))
         assert (gh, gw) == (6, 9)
@@ -59,7 +63,7 @@ def test_vit_tiny_encoder_golden(golden):
         assert e < tol, (dt, e)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
 def test_full_forward_golden(golden, cfg, dtype):
     """ViT-L, 2 pairs of 182x196: every data-dict output against the reference's (fp32) outputs."""
     dev = _dev()
@@ -88,26 +92,54 @@ def test_full_forward_golden(golden, cfg, dtype):
     assert torch.isfinite(data["inliers"]).all()
 
 
-def test_full_size_pair_vs_oracle(cfg):
+_ORACLE_720 = {}
+
+
+def _oracle_720(cfg, sd, batch):
+    """CPU oracle on the 720x540 pair (~20 s): computed once per session, shared by the dtype variants."""
+    from oracle import mickey_oracle as O
+    if "d" not in _ORACLE_720:
+        odata = {k: v.clone() for k, v in batch.items()}
+        with torch.no_grad():
+            odata.update(O.compute_correspondences(sd, cfg, odata))
+        _ORACLE_720["d"] = odata
+    return _ORACLE_720["d"]
+
+
+def test_heads_fp32_option_matches_reference_split(golden, cfg):
+    """AMD.HEADS_DTYPE: fp32 with a 16-bit encoder is the reference's own precision split (fp16 ViT, fp32 heads,
+    mickey_extractor.py:49-56): it must land inside the reference's fp16 noise floor."""
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    g = golden("full_forward")
+    model, _ = _model(cfg, "fp16", HEADS_DTYPE="fp32")
+    data = {k: v.to(dev) for k, v in syn.synthetic_batch(B=2, H=182, W=196, seed=1234).items()}
+    model.compute_correspondences(data)
+    errs = {k: rel(data[k], g[k]) for k in KEYS}
+    print("fp16 encoder + fp32 heads", {k: "%.2e" % v for k, v in errs.items()})
+    tol = TOL[torch.float16]
+    for k in KEYS:
+        assert errs[k] < tol[k.rstrip("01").replace("depth_kp", "depth")], (k, errs[k])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_full_size_pair_vs_oracle(cfg, dtype):
     """One 720x540 pair (51x38 grid, n = 1938) against the CPU oracle run here on the same seeded
-    weights and inputs (extractor + matcher; ~20 s of CPU)."""
+    weights and inputs (extractor + matcher; ~20 s of CPU).  fp32 = the exact parity mode: <= 1e-4 everywhere."""
     dev = _dev()
     from mickey_amd import synthetic as syn
     from oracle import mickey_oracle as O
-    model, sd = _model(cfg, "bf16")
+    model, sd = _model(cfg, dtype)
     batch = syn.synthetic_batch(B=1, H=720, W=540, seed=1234)
     data = {k: v.to(dev) for k, v in batch.items()}
     model.compute_correspondences(data)
-    odata = {k: v.clone() for k, v in batch.items()}
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    with torch.no_grad():
-        odata.update(O.compute_correspondences(sd, cfg, odata))
-    tol = TOL[torch.bfloat16]
+    odata = _oracle_720(cfg, sd, batch)
+    tol = TOL[model.lp_dtype]
     errs = {k: rel(data[k], odata[k]) for k in KEYS}
-    print("720x540", {k: "%.2e" % v for k, v in errs.items()})
+    print("720x540", dtype, {k: "%.2e" % v for k, v in errs.items()})
     for k in KEYS:
         base = k.rstrip("01").replace("depth_kp", "depth")
-        assert errs[k] < 1.5 * tol[base], (k, errs[k])
+        assert errs[k] < (1.0 if dtype == "fp32" else 1.5) * tol[base], (k, errs[k])
     assert data["scores"].shape == (1, 1938, 1938)
     # row arg-max of the score matrix: identical wherever the oracle's top-2 gap exceeds the noise floor
     top2 = odata["scores"].topk(2, dim=2).values
