@@ -38,6 +38,19 @@ int mk_version(void);
 const char* mk_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input pipeline (the caller in FRONT of the hot path)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Decoded frames -> model input: replaces cv2.resize + float + permute(2,0,1) + /255 of read_color_image
+ * (lib/datasets/utils.py:61-78; same in demo_inference.py:12-29) for n frames at once.
+ *   src  uint8 [n, Hs, Ws, 3] RGB on the device, frame stride stride_img bytes (>= Hs*Ws*3)
+ *   dst  fp32  [n, 3, H, W] in [0, 1]
+ * Bilinear, half-pixel centres, edge clamp (cv2 INTER_LINEAR sampling, fp32 weights); Hs == H and Ws == W is the
+ * identity resize and gives exactly float(v) / 255. */
+int mk_preprocess_u8(const unsigned char* src, long long stride_img, int n, int Hs, int Ws, float* dst, int H, int W,
+                     mk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Encoder: DINOv2 ViT/14 (reference lib/models/MicKey/modules/DINO_modules/)
  * ---------------------------------------------------------------------------------------------- */
 
@@ -187,11 +200,14 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  *   invalid int32 [1] or NULL: OR-ed with 1 when torch.multinomial would have raised (a NaN / inf /
  *          negative probability, or a row without any positive cell) -- the reference then returns
  *          the zero pose for the whole batch (probabilisticProcrustes.py:331-336)
- *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k), 16-byte aligned */
+ *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k), 16-byte aligned
+ *   pair_base  GLOBAL index of pair 0 of this call.  The Philox streams are keyed by (seed, offset, global pair index,
+ *          draw, cell), so a batch may be split arbitrarily -- over calls or over the GPUs of a node -- without changing
+ *          any pair's draws: pair i of a B = 32 call and the same pair alone with pair_base = i sample identically. */
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k);
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
                     const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
-                    long long ncell, int k, mk_stream_t stream);
+                    long long ncell, int k, int pair_base, mk_stream_t stream);
 
 /* *counter += inc on the stream.  `offset_dev` of mk_exprace_topk / mk_ransac_hypotheses (may be NULL) is such a
  * counter: the Philox stream offset used is offset + *offset_dev, read on the device when the kernel runs, so a
@@ -212,11 +228,13 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
  * draw 3 of k without replacement weighted by wts (exponential race; noise3 = NULL: Philox, else fp32
  * [R*it_ransac, k] injected; idx3_in != NULL injects the 3 indices directly), fit R,t by Kabsch on the
  * 3 point pairs, score = sum_j sigmoid(5/th * (th - sqrt(|R X_j + t - Y_j|^2 + 1e-6))).
- *   Rh [R*it_ransac, 9], th [R*it_ransac, 3], score [R*it_ransac], idx3 int32 [R*it_ransac, 3] (out) */
+ *   Rh [R*it_ransac, 9], th [R*it_ransac, 3], score [R*it_ransac], idx3 int32 [R*it_ransac, 3] (out)
+ *   set_base  GLOBAL index of correspondence set 0 of this call (= pair_base * rows_per_pair): keys the Philox streams of
+ *          the 3-samples the same way as pair_base in mk_exprace_topk */
 int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev,
                          float th_soft, float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k,
-                         mk_stream_t stream);
+                         long long set_base, mk_stream_t stream);
 
 /* Arg-max over a pair's hypotheses, <= num_ref rounds of {hard-inlier recount, masked weighted Kabsch},
  * final confidence (probabilisticProcrustes.py:275-303, loss/solvers.py:13-26, training_utils.py:71-75).

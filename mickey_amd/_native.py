@@ -20,6 +20,7 @@ _CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 SIGNATURES = {
     "mk_version": ("i", ""),
     "mk_last_error": ("s", ""),
+    "mk_preprocess_u8": ("i", "pliiipiip"),
     "mk_gemm": ("i", "pipippiiiiiiip"),
     "mk_gemm_grouped": ("i", "pilpilplpiliiiiiiip"),
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
@@ -41,10 +42,10 @@ SIGNATURES = {
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iii"),
-    "mk_exprace_topk": ("i", "ppuupppppiilip"),
+    "mk_exprace_topk": ("i", "ppuupppppiiliip"),
     "mk_counter_add": ("i", "pup"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),
-    "mk_ransac_hypotheses": ("i", "pppppuupfppppiiip"),
+    "mk_ransac_hypotheses": ("i", "pppppuupfppppiiilp"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),
     "mk_pose_finalize": ("i", "ppppip"),
 }

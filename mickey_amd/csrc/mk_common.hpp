@@ -95,6 +95,22 @@ __device__ __forceinline__ void glds16_cp(const void* gsrc, void* lds_wave_base)
   __builtin_amdgcn_global_load_lds(MK_GLOBAL_PTR(gsrc), MK_LDS_PTR(lds_wave_base), 16, 0, AUX);
 }
 
+// The same copy with the address split as the hardware takes it: wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte
+// offset (global_load_lds_dwordx4 v_off, s[base:base+1]).  The builtin always materialises a 64-bit per-lane address (one
+// v_lshl_add_u64 + often a v_add per piece: measured ~30 cycles per piece of matrix-pipe idle time when a piece follows
+// every MFMA); here a piece costs two SALU moves and the DMA instruction.  M0 (the LDS destination) is written and
+// restored inside the statement (hipcc reserves it); the DMA is invisible to hipcc's vmcnt bookkeeping: the caller waits
+// with its own s_waitcnt vmcnt(N).  sbase and lds_dst must be provably wave-uniform (kernel arguments, blockIdx
+// expressions, readfirstlane results).
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, void* lds_dst) {
+  unsigned keep;
+  const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds)
+               : "memory");
+}
+
 // XOR swizzle of 16-byte chunks inside 128-byte LDS rows: chunk' = chunk ^ ((row >> 1) & 7).
 // Conflict-free for ds_read_b128 fragment reads where a 16-lane group covers 16 distinct rows at one
 // logical chunk (MI355X: 64 banks x 4 B, b128 reads serviced in 4 groups of 16 lanes).

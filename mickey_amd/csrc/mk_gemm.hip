@@ -118,16 +118,13 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   const long long big_tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * groups;
   bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
   // the 256x256 kernels address operands with 32-bit element offsets and run a software pipeline of >= 2 K stages
+  // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
                     (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
   if (dtype == MK_F32) return launch_f32(p, groups, AMODE, st);   // exact parity mode: one plain schedule
   int sched = g_schedule;
   if (sched == 0) sched = (big && k_ok) ? MK_GEMM_DEFAULT_BIG : 1;
   if (!k_ok) sched = 1;
-  if ((sched == 12 || sched == 13) && AMODE == A_DENSE && dtype == MK_BF16) return launch_w4_variant(p, groups, st, g_band_m, sched - 11);
-  if (sched == 12 || sched == 13) sched = 10;
-  if (sched == 11 && p.K < 192) sched = 10;
-  if (sched == 11) return launch_w4k32(p, groups, dtype, AMODE, st, g_band_m);
   if (sched == 10) return launch_w4(p, groups, dtype, AMODE, st, g_band_m);
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
   return dtype == MK_BF16 ? launch_small<__bf16, AMODE>(p, groups, st) : launch_small<_Float16, AMODE>(p, groups, st);
@@ -169,8 +166,8 @@ int mk_gemm_set_tile(int mode) {
     g_band_m = mode - 400 > 0 ? mode - 400 : 1;
     return MK_OK;
   }
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 7 || mode == 10 || mode == 11 || mode == 12 || mode == 13,
-               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 7 8-wave ping-pong, 10 / 11 one wave per SIMD with 2 x K64 / 5 x K32 stages)", mode);
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 7 || mode == 10,
+               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 7 8-wave ping-pong, 10 one wave per SIMD)", mode);
   g_schedule = mode;
   return MK_OK;
 }

@@ -474,8 +474,6 @@ int num_cus();
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
 int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)
 int launch_w4(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
-int launch_w4_variant(const GemmParams& p, int groups, hipStream_t st, int band_m, int dsch);   // dev (bf16 dense only)
-int launch_w4k32(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);   // needs K >= 192
 
 }  // namespace gemm
 }  // namespace mk

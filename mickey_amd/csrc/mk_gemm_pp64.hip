@@ -52,13 +52,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     const int rw = (wave * 4 + j) * 8 + srow;
     int n = n0 + rw;
     n = n < p.N ? n : p.N - 1;
-    woff[j] = (unsigned)n * (unsigned)p.ldw + swz8(rw, sp) * 8;
+    woff[j] = ((unsigned)n * (unsigned)p.ldw + swz8(rw, sp) * 8) * (unsigned)sizeof(T);   // bytes (< 2^32: see launch())
     const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
     int m = m0 + ra;
     avalid[j] = m < p.M;
     m = avalid[j] ? m : p.M - 1;
     if (AMODE == A_DENSE) {
-      aoff[j] = (unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8;
+      aoff[j] = ((unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
       ay[j] = ax[j] = 0;
     } else {
       const int pix = m % (p.H * p.Wd);
@@ -68,34 +68,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     }
   }
   auto dma_w1 = [&](int s, int j) {
-    glds16(W + (woff[j] + (unsigned)(s * BK)), smem + (s & 1) * STAGE_BYTES + A_BYTES + (wave * 4 + j) * 1024);
+    // wave-uniform base (SGPRs) + the lane's constant 32-bit byte offset: no VALU instruction per piece
+    glds16_sv(W + s * BK, woff[j], smem + (s & 1) * STAGE_BYTES + A_BYTES + (wave * 4 + j) * 1024);
   };
-  auto dma_a1 = [&](int s, int j) {
-    char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
-    const int k0 = s * BK;
-    if (AMODE == A_DENSE) {
-      glds16(A + (aoff[j] + (unsigned)k0), dst);
-    } else {
-      const int kc = 9 * p.C1;
-      const T* src;
-      int cs, c0, dy, dx;
+  // conv: which tap / source a K stage belongs to is wave-uniform and the same for the 4 pieces of the stage: computed
+  // once per stage (it holds two integer divisions), not once per piece inside the MFMA slot
+  struct Tap { const T* src; int cs, c0, dy, dx; };
+  auto conv_tap = [&](int s) {
+    Tap t = {nullptr, 0, 0, 0, 0};
+    if (AMODE != A_DENSE) {
+      const int k0 = s * BK, kc = 9 * p.C1;
       if (k0 < kc) {
         const int tap = k0 / p.C1;
-        c0 = k0 - tap * p.C1;
-        dy = tap / 3 - 1;
-        dx = tap % 3 - 1;
-        src = A;
-        cs = p.C1;
+        t.c0 = k0 - tap * p.C1;
+        t.dy = tap / 3 - 1;
+        t.dx = tap % 3 - 1;
+        t.src = A;
+        t.cs = p.C1;
       } else {
-        c0 = k0 - kc;
-        dy = dx = 0;
-        src = A2;
-        cs = p.C2;
+        t.c0 = k0 - kc;
+        t.src = A2;
+        t.cs = p.C2;
       }
+    }
+    return t;
+  };
+  auto dma_a1 = [&](int s, int j, const Tap& t) {
+    char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
+    if (AMODE == A_DENSE) {
+      glds16_sv(A + s * BK, aoff[j], dst);
+    } else {
       const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
-      const int yy = ay[j] + dy, xx = ax[j] + dx;
+      const int yy = ay[j] + t.dy, xx = ax[j] + t.dx;
       const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-      const T* sp_ = ok ? src + ((long long)aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
+      const T* sp_ = ok ? t.src + ((long long)aoff[j] + t.dy * p.Wd + t.dx) * t.cs + t.c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
       glds16(sp_, dst);
     }
   };
@@ -104,8 +110,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     for (int j = 0; j < 4; ++j) dma_w1(s, j);
   };
   auto dma_a = [&](int s) {
+    const Tap t = conv_tap(s);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_a1(s, j);
+    for (int j = 0; j < 4; ++j) dma_a1(s, j, t);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s go out BETWEEN them (behind MFMA 3, 11, 19, 27), pinned
   auto mfma32 = [&](const V8* wf, const V8* xf, auto dma, int s) {
     constexpr bool DMA = decltype(dma)::value;
+    const Tap t = DMA ? conv_tap(s) : Tap{nullptr, 0, 0, 0, 0};
     __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
       if (DMA && (q & 7) == 3) {
         __builtin_amdgcn_sched_barrier(0);
-        dma_a1(s, q >> 3);
+        dma_a1(s, q >> 3, t);
         __builtin_amdgcn_sched_barrier(0);
       }
     }

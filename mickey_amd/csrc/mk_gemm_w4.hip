@@ -10,24 +10,30 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 // One wave per SIMD: 256x256 tile, FOUR waves (2 x 2), each wave owns a 128x128 block of C = 16 accumulators of
 // v_mfma_f32_32x32x16 = 256 registers (the whole 512-entry register file of its SIMD is this wave's: 256 AGPR
-// accumulators, fragments and addresses in VGPRs).
-// Why (tools/micro/r2_probe.hip, measured on MI355X): (1) VALU-class issue bandwidth is per SIMD, ~1 instruction per
-// 4.7 cycles; a v_mfma_f32_32x32x16 takes one of those slots but 32 cycles of matrix pipe, so a single in-order wave can
-// issue ~5 other instructions per MFMA for free, and this loop needs 0.5 ds_read_b128 + 0.25 LDS-DMA piece per MFMA;
-// (2) an LDS-DMA piece issued BETWEEN a wave's MFMAs costs ~12 cycles, issued after them (as the 8-wave ping-pong did at
-// the end of its compute slot) it is serial; (3) the L2 -> LDS DMA path sustains 70 B/clk/CU, this loop needs 32.
-// The 128x128 wave tile also reads a third less LDS per flop than 128x64.  No wave-role alternation, no priorities, ONE
-// barrier per K = 64 stage, and no latency is exposed at it: the barrier sits in front of the LAST k-step of a stage,
-// whose 16 MFMAs run from registers while the first fragments of the next stage are being read.
+// accumulators, fragments and addresses in VGPRs).  The ALTERNATIVE large-problem schedule (mk_gemm_set_tile(10)); the
+// default is the 8-wave ping-pong of mk_gemm_pp64.hip, which measures 7-15 % faster on the encoder shapes.
+// Idea (tools/micro/r2_probe.hip): VALU-class issue bandwidth is per SIMD, ~1 instruction per 4.7 cycles; a 32x32x16 MFMA
+// takes one of those slots but 32 cycles of matrix pipe, so a single in-order wave should be able to issue the 0.5
+// ds_read_b128 + 0.25 LDS-DMA piece per MFMA this loop needs in the shadow of its own MFMAs -- no wave-role alternation,
+// no priorities, ONE barrier per K = 64 stage placed in front of the stage's LAST k-step, whose 16 MFMAs run from
+// registers while the next stage's first fragments are read; the 128x128 wave tile reads a third less LDS per flop.
 //   stage s (K = 64, LDS buffer s & 1) = k-steps (s,0..3) of K = 16;  fragment sets F0 / F1 (8 x b128 each)
 //   step (s,kk), kk < 3:  16 MFMAs, behind each of the first 8 a fragment read of (s,kk+1), behind the next ones a DMA piece
 //   step (s,3):  vmcnt(0) [stage s+1 landed]  lgkmcnt(0)  s_barrier   [every wave is done reading stage s]
 //                16 MFMAs | reads (s+1,0) | DMA pieces of stage s+2 (into the buffer of stage s)
 // The 16 DMA pieces of stage s+2 are issued in steps (s,3): 6, (s+1,0): 6, (s+1,1): 4: a wave has at most 16 in flight
 // and drains them once per stage.
-// DSCH: how the 16 DMA pieces of stage s+2 are spread over the k-steps (s,3), (s+1,0), (s+1,1): 0 = 6 + 6 + 4,
-// 1 = all 16 in (s,3) (one behind every MFMA), 2 = 8 + 8
-template <typename T, int AMODE, int DSCH>
+// What it measures (tools/micro/r2_kstep.hip replays one k-step of this loop, ns per k-step on MI355X, random operands):
+// 16 MFMAs alone 290 (= 18.1 ns per MFMA: the matrix pipe at the sustained clock) | + 8 fragment reads 279 (free) | the
+// MFMAs consuming the fragments read one step earlier 308 (wherever the lgkmcnt wait sits, or without it) | + 6 DMA pieces
+// 364 (9 ns each even in the SGPR-base form: a vector-memory instruction is NOT absorbed by the MFMA it follows).  The
+// kernel's K loop runs at exactly that rate (2740 cycles per stage; s_memtime brackets put only ~130 of them at the
+// stage-boundary waits), i.e. ~1.4 PFLOP/s in the loop and 0.94-1.14 PFLOP/s per launch with prologue, epilogue and tail.
+// Tried on top (all measured, none faster): a 5-deep ring of K = 32 stages with counted vmcnt(24) (-5 %), all 16 pieces
+// right behind the barrier (-3..-5 %), 8 + 8 (same), sched_group_barrier instead of pinned program order (the compiler
+// clusters reads and pieces behind the second MFMA: -4 %), 16x16x32 MFMAs with 256 f32x4 accumulators (register
+// allocator shuffles accumulators between AGPRs and VGPRs inside the loop).
+template <typename T, int AMODE>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_m) {
   using V8 = typename Lp<T>::V8;
   constexpr int BM = 256, BN = 256;
@@ -57,12 +63,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
     const int r = (wave * 8 + j) * 8 + srow;
     int n = n0 + r;
     n = n < p.N ? n : p.N - 1;
-    woff[j] = (unsigned)n * (unsigned)p.ldw + swz8(r, sp) * 8;
+    woff[j] = ((unsigned)n * (unsigned)p.ldw + swz8(r, sp) * 8) * (unsigned)sizeof(T);   // bytes (< 2^32: see launch())
     int m = m0 + r;
     const bool ok = m < p.M;
     m = ok ? m : p.M - 1;
     if (AMODE == A_DENSE) {
-      aoff[j] = (unsigned)m * (unsigned)p.lda + swz8(r, sp) * 8;
+      aoff[j] = ((unsigned)m * (unsigned)p.lda + swz8(r, sp) * 8) * (unsigned)sizeof(T);
     } else {
       const int pix = m % (p.H * p.Wd);
       ay[j] = pix / p.Wd;
@@ -75,10 +81,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
   auto dma1 = [&](int s, int which, int j) {
     char* dst = smem + (s & 1) * STAGE_BYTES + which * A_BYTES + (wave * 8 + j) * 1024;
     const int k0 = s * BK;
+    // dense operands: wave-uniform base (operand + k offset, SGPRs) + this lane's constant 32-bit byte offset, so the
+    // address costs no VALU instruction per piece (global_load_lds v_off, s[base:base+1])
     if (which == 1) {
-      glds16(W + (woff[j] + (unsigned)k0), dst);
+      glds16_sv(W + k0, woff[j], dst);
     } else if (AMODE == A_DENSE) {
-      glds16(A + (aoff[j] + (unsigned)k0), dst);
+      glds16_sv(A + k0, aoff[j], dst);
     } else {
       const int kc = 9 * p.C1;
       const T* src;
@@ -125,8 +133,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
   V8 f0[8], f1[8];   // fragment sets: [0..3] W, [4..7] activations
   // One k-step: 16 MFMAs on `cur`, each followed by at most ONE memory instruction -- a fragment read of the next
   // k-step behind each of the first 8 (the youngest read is 8 MFMAs old when the next step needs it), an LDS-DMA piece
-  // behind the following ones -- and a scheduling barrier that pins exactly this order (left to itself, or with sched_group_barrier, the compiler clusters the 8 reads and the DMA pieces behind the
-  // second MFMA and the matrix pipe idles for ~400 of the step's ~900 cycles while they issue: 929 vs 1104 TFLOP/s).
+  // behind the following ones -- and a scheduling barrier that pins exactly this order.
   auto kstep = [&](const V8* cur, V8* nxt, auto reads, int rpar, int rkk, int ds, auto dq0, auto d0, auto ndma) {
     constexpr bool READS = decltype(reads)::value;
     constexpr int DQ0 = decltype(dq0)::value, D0 = decltype(d0)::value, NDMA = decltype(ndma)::value;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
     }
   };
   // pieces issued in steps (s,3) | (s+1,0) | (s+1,1) and the MFMA slot of the first one
-  constexpr int N3 = DSCH == 0 ? 6 : DSCH == 1 ? 16 : 8, NA = DSCH == 0 ? 6 : DSCH == 1 ? 0 : 8, NB = DSCH == 0 ? 4 : 0;
-  constexpr int Q3 = DSCH == 1 ? 0 : 8;
+  constexpr int N3 = 6, NA = 6, NB = 4;
+  constexpr int Q3 = 8;
   using I0 = std::integral_constant<int, 0>;
   using I8 = std::integral_constant<int, 8>;
   // one K = 64 stage; NEXT1: stage s+1 exists, NEXT2: stage s+2 exists
@@ -164,9 +171,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
   for (int i = 0; i < 16; ++i) dma_piece(0, i);
 #pragma unroll
   for (int i = 0; i < N3; ++i) dma_piece(1, i);
-  if constexpr (N3 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N3 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -178,12 +183,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams p, int band_
   epilogue32<T>(p, acc, smem + wave * 32768, m0, n0, wm, wn, lane, g);
 }
 
-template <typename T, int AMODE, int DSCH = 0>
+template <typename T, int AMODE>
 int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   constexpr int LDS = 2 * 512 * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<T, AMODE, DSCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -191,17 +196,12 @@ int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
     attr_done = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  hipLaunchKernelGGL((gemm_w4_kernel<T, AMODE, DSCH>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p, band_m);
+  hipLaunchKernelGGL((gemm_w4_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p, band_m);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
 
 }  // namespace
-
-// dev: DMA-distribution variants of the bf16 dense kernel (mk_gemm_set_tile 12 / 13)
-int launch_w4_variant(const GemmParams& p, int groups, hipStream_t st, int band_m, int dsch) {
-  return dsch == 1 ? launch_t<__bf16, A_DENSE, 1>(p, groups, st, band_m) : launch_t<__bf16, A_DENSE, 2>(p, groups, st, band_m);
-}
 
 int launch_w4(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m) {
   if (amode == A_DENSE)

@@ -75,11 +75,12 @@ struct TopkWork {
   int* redo;                 // [1] set when a row collected fewer than k candidates above an analytic threshold
   unsigned long long* cand;  // [R][CAND_MAX]
   int* invalid;              // [1] or null
+  int pair_base;             // global index of pair 0 of this call (keys the Philox streams)
 };
 
 __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsigned k0, unsigned k1, unsigned off_lo,
                                          unsigned off_hi, float p, long long c, long long ncell, int b, int rows_per_pair,
-                                         int grp, float key[RG]) {
+                                         int grp, float key[RG], int pair_base) {
   if (noise) {
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
@@ -87,7 +88,7 @@ __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsign
       key[q] = r < rows_per_pair ? p / noise[((long long)b * rows_per_pair + r) * ncell + c] : 0.f;
     }
   } else {
-    const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, (unsigned)(c >> 32) ^ off_hi, (unsigned)(b * 64 + grp), off_lo});
+    const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, (unsigned)(c >> 32) ^ off_hi, (unsigned)((b + pair_base) * 64 + grp), off_lo});
     key[0] = race_key(p, rnd.x);
     key[1] = race_key(p, rnd.y);
     key[2] = race_key(p, rnd.z);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
     const float pv = pb[c];
     if (!(pv > 0.f) || isinf(pv)) continue;
     float key[RG];
-    row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key);
+    row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key, w.pair_base);
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int r = grp * RG + q;
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
                                                          const unsigned long long* __restrict__ offp, float th_soft,
                                                          float* __restrict__ Rh, float* __restrict__ th,
                                                          float* __restrict__ score, int* __restrict__ idx3, int it_ransac, int k,
-                                                         int nsplit) {
+                                                         int nsplit, long long set_base) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // X[k*3] | Y[k*3] | w[k]
   add_device_offset(off_lo, off_hi, offp);
   float* sX = lds;
@@ -503,7 +504,8 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
 #pragma unroll
           for (int q = 0; q < 4; ++q) e[q] = base + q < k ? noise3[hyp * k + base + q] : 1.f;
         } else {
-          const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(base >> 2), (unsigned)hyp, (unsigned)(hyp >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
+          const long long gh = hyp + set_base * it_ransac;   // GLOBAL hypothesis index: draws do not depend on how a batch is split
+          const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(base >> 2), (unsigned)gh, (unsigned)(gh >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
           e[0] = exp1(rnd.x); e[1] = exp1(rnd.y); e[2] = exp1(rnd.z); e[3] = exp1(rnd.w);
         }
 #pragma unroll
@@ -732,7 +734,7 @@ int mk_counter_add(unsigned long long* counter, unsigned long long inc, mk_strea
 
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
                     const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
-                    long long ncell, int k, mk_stream_t stream) {
+                    long long ncell, int k, int pair_base, mk_stream_t stream) {
   MK_CHECK_ARG(p && idx && cnt && work, "mk_exprace_topk: null pointer");
   MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && rows_per_pair <= 64 * RG && ncell > 0 && ncell < (1LL << 31) && k > 0 &&
                    k <= CAND_MAX / 2,
@@ -742,6 +744,7 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   const int R = B * rows_per_pair;
   TopkWork w = carve(work, R, B);
   w.invalid = invalid;
+  w.pair_base = pair_base;
   const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + 1;
   hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand | phist | redo are contiguous
   MK_CHECK_LAUNCH();
@@ -784,7 +787,8 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
 
 int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const float* noise3, const int* idx3_in,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev, float th_soft,
-                         float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k, mk_stream_t stream) {
+                         float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k, long long set_base,
+                         mk_stream_t stream) {
   MK_CHECK_ARG(X && Y && wts && Rh && th && score && idx3, "mk_ransac_hypotheses: null pointer");
   MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 28 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 5485)");
   const int nsplit = it_ransac >= 16 ? 4 : 1;
@@ -795,7 +799,7 @@ int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const
   }
   hipLaunchKernelGGL(hypotheses_kernel, dim3(nsets * nsplit), dim3(256), lds, (hipStream_t)stream, X, Y, wts, noise3, idx3_in,
                      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), offset_dev, th_soft, Rh, th,
-                     score, idx3, it_ransac, k, nsplit);
+                     score, idx3, it_ransac, k, nsplit, set_base);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -26,6 +26,8 @@ def shard_batch(data, rank, world):
             out[k] = v[lo:hi]
         else:
             out[k] = v
+    # global index of the shard's first pair: keys the samplers' Philox streams, so sharded == unsharded poses
+    out["pair_base"] = int(data.get("pair_base", 0)) + lo
     return out
 
 

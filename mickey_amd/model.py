@@ -258,8 +258,10 @@ class MickeyRelativePose(nn.Module):
         from . import ops
         self._calls += 1
         ops.counter_add(self._ctr, 2)
+        # data["pair_base"] (optional, int): global index of this batch's first pair -- a rank of a sharded batch passes its
+        # shard offset so that the poses do not depend on the sharding (mickey_amd.distributed.shard_batch sets it)
         sol = pipeline.solve(self.cfg, data["final_scores"], data["kps0"], data["depth_kp0"], data["kps1"], data["depth_kp1"],
-                             K0, K1, seed=self.seed, offset=0, offset_dev=self._ctr)
+                             K0, K1, seed=self.seed, offset=0, offset_dev=self._ctr, pair_base=int(data.get("pair_base", 0)))
         if return_inliers:
             return sol["R"], sol["t"], sol["inliers"], pipeline.inliers_list(sol)
         return sol["R"], sol["t"], sol["inliers"]
@@ -287,8 +289,8 @@ class MickeyRelativePose(nn.Module):
             self._ctr.fill_(2 * self._calls)
 
     _GRAPH_INPUTS = ("image0", "image1", "K_color0", "K_color1")
-    _LEAN_KEYS = ("R", "t", "inliers", "depth0_map", "depth1_map", "scr0", "scr1", "kps0", "kps1", "depth_kp0", "depth_kp1",
-                  "kps0_shape", "kps1_shape", "down_factor")
+    _LEAN_KEYS = ("R", "t", "inliers", "final_scores", "depth0_map", "depth1_map", "scr0", "scr1", "kps0", "kps1", "depth_kp0",
+                  "depth_kp1", "kps0_shape", "kps1_shape", "down_factor")
 
     def _wants_graph(self, data, return_inliers):
         mode = self.graph_mode
@@ -307,12 +309,14 @@ class MickeyRelativePose(nn.Module):
         pair: 7.9 -> 7.3 ms).  Inputs are copied into static buffers and everything written into `data` is cloned out of
         the graph's memory pool, so results never alias a later call."""
         dev = self._anchor.device
-        key = tuple((k, tuple(data[k].shape)) for k in self._GRAPH_INPUTS)
+        key = tuple((k, tuple(data[k].shape)) for k in self._GRAPH_INPUTS) + (("pair_base", int(data.get("pair_base", 0))),)
         entry = self._graphs.get(key)
         if entry is None:
             static = {k: torch.empty(data[k].shape, device=dev, dtype=torch.float32) for k in self._GRAPH_INPUTS}
             for k in self._GRAPH_INPUTS:
                 static[k].copy_(data[k])
+            if "pair_base" in data:
+                static["pair_base"] = int(data["pair_base"])   # a kernel argument: part of the captured graph (and of its key)
             # warm-up outside the capture (lazy weight preparation, workspace allocation, kernel attributes) without
             # consuming random-stream positions
             calls = self._calls
@@ -337,7 +341,7 @@ class MickeyRelativePose(nn.Module):
         graph.replay()
         # everything the forward wrote is cloned out of the graph's pool (a later replay overwrites it); in LEAN mode only
         # what the inference callers read (submission.py:40-45, demo_inference.py:120-123): poses, confidence, depth / score
-        # maps and keypoints -- not the three [B, n, n] score matrices and the descriptors
+        # maps and keypoints, plus final_scores (the one [B, n, n] matrix LEAN keeps) -- not the descriptors
         keep = self._LEAN_KEYS if self.lean else None
         for k, v in gdata.items():
             if k not in self._GRAPH_INPUTS and (keep is None or k in keep):

@@ -18,6 +18,16 @@ def _chk(t, dtype=None):
     return t
 
 
+def preprocess_u8(frames, H, W, out=None):
+    """uint8 [n, Hs, Ws, 3] device frames -> fp32 [n, 3, H, W] in [0, 1] (resize + /255 + CHW, mk_preprocess_u8)."""
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+    n, Hs, Ws, _ = frames.shape
+    if out is None:
+        out = torch.empty((n, 3, H, W), device=frames.device, dtype=torch.float32)
+    call("mk_preprocess_u8", ptr(frames), Hs * Ws * 3, n, Hs, Ws, ptr(out), H, W, stream())
+    return out
+
+
 def gemm_set_tile(mode):
     """Dev knob (mickey_hip_dev.h): 0 auto, 1 force 128x128, 7 force the 8-wave ping-pong, 10 force one wave per SIMD."""
     call("mk_gemm_set_tile", int(mode))
@@ -197,7 +207,7 @@ def counter_add(counter, inc):
     call("mk_counter_add", ptr(counter), int(inc), stream())
 
 
-def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None):
+def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None, pair_base=0):
     """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
     p, noise = _c(p, noise)
     _chk(p, torch.float32)
@@ -207,7 +217,7 @@ def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None
     cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
     work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k),), device=dev, dtype=torch.uint8)
     call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(offset_dev), ptr(idx), ptr(cnt), ptr(invalid), ptr(work),
-         B, rows_per_pair, ncell, k, stream())
+         B, rows_per_pair, ncell, k, int(pair_base), stream())
     return idx, cnt
 
 
@@ -230,7 +240,7 @@ def gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, ro
     return X, Y, wts, corr
 
 
-def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0, offset_dev=None):
+def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, seed=0, offset=0, offset_dev=None, set_base=0):
     X, Y, wts, noise3, idx3_in = _c(X, Y, wts, noise3, idx3_in)
     nsets, k, _ = X.shape
     dev = X.device
@@ -240,7 +250,7 @@ def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, 
     score = torch.empty((nh,), device=dev, dtype=torch.float32)
     idx3 = torch.empty((nh, 3), device=dev, dtype=torch.int32)
     call("mk_ransac_hypotheses", ptr(X), ptr(Y), ptr(wts), ptr(noise3), ptr(idx3_in), int(seed), int(offset), ptr(offset_dev),
-         float(th_soft), ptr(Rh), ptr(th), ptr(score), ptr(idx3), nsets, it_ransac, k, stream())
+         float(th_soft), ptr(Rh), ptr(th), ptr(score), ptr(idx3), nsets, it_ransac, k, int(set_base), stream())
     return Rh, th, score, idx3
 
 

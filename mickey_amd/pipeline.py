@@ -152,9 +152,10 @@ def match(W, cfg, dsc0, dsc1, scr0, scr1, lean=False):
 
 
 def solve(cfg, final_scores, kps0, depth0, kps1, depth1, K0, K1, seed=0, offset=0, noise_outer=None, noise_inner=None,
-          idx3_in=None, debug=False, offset_dev=None):
+          idx3_in=None, debug=False, offset_dev=None, pair_base=0):
     """reference probabilisticProcrustes.py:183-348 on device.  Returns a dict with R [B,3,3], t [B,1,3],
-    inliers [B,1] and the intermediates needed for the inlier list."""
+    inliers [B,1] and the intermediates needed for the inlier list.  pair_base = global index of pair 0 (keys the
+    Philox streams: sharding a batch over calls / GPUs does not change any pair's draws)."""
     P = cfg["PROCRUSTES"]
     it_m, it_r, ns, k3 = int(P["IT_MATCHES"]), int(P["IT_RANSAC"]), int(P["NUM_SAMPLED_MATCHES"]), int(P["NUM_CORR_3D_3D"])
     if k3 != 3:
@@ -163,10 +164,11 @@ def solve(cfg, final_scores, kps0, depth0, kps1, depth1, K0, K1, seed=0, offset=
     dev = final_scores.device
     invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
     idx, cnt = ops.exprace_topk(final_scores.reshape(B, n0 * n1), it_m, ns, noise=noise_outer, seed=seed, offset=offset,
-                                invalid=invalid, offset_dev=offset_dev)
+                                invalid=invalid, offset_dev=offset_dev, pair_base=pair_base)
     X, Y, w, corr = ops.gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, it_m)
     Rh, th, score, idx3 = ops.ransac_hypotheses(X, Y, w, it_r, float(P["TH_SOFT_INLIER"]), noise3=noise_inner,
-                                                idx3_in=idx3_in, seed=seed, offset=offset + 1, offset_dev=offset_dev)
+                                                idx3_in=idx3_in, seed=seed, offset=offset + 1, offset_dev=offset_dev,
+                                                set_base=pair_base * it_m)
     R, t, conf, best, mask, rounds, invalid = ops.refine_pose(X, Y, Rh, th, score, B, it_m, it_r, float(P["TH_INLIER"]),
                                                               int(P["NUM_REFINEMENTS"]), k3, invalid=invalid)
     out = {"R": R, "t": t, "inliers": conf, "best": best, "mask": mask, "corr": corr, "weights": w, "invalid": invalid,

@@ -189,7 +189,12 @@ def golden_submission_lines():
     print("submission_lines: %d lines, e.g. %s" % (len(lines), lines[0]))
 
 
-def main():
+def main(out_dir=None):
+    """out_dir: write the fixtures somewhere else (tests/test_oracle_golden.py regenerates them into a temp dir and
+    compares with the committed ones)."""
+    global GOLD
+    if out_dir is not None:
+        GOLD = out_dir
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     cfg = default_cfg()
@@ -198,9 +203,10 @@ def main():
     gold_matcher(cfg, model)
     gold_solver(cfg, model)
     golden_submission_lines()
+    ref_shim.uninstall()
     print("golden fixtures written to", GOLD)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
 

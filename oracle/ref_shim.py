@@ -18,21 +18,41 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "lib", "models", "MicKey"))
 
 
-def install():
-    if not available():
-        raise RuntimeError("reference tree not found at %s" % REF_ROOT)
-    if REF_ROOT not in sys.path:
-        # the reference's top-level package is called `lib`; this repo ships a drop-in package of the
-        # same name, so the reference must win while the shim is active
-        sys.path.insert(0, REF_ROOT)
+def _purge_lib():
     for name in [m for m in sys.modules if m == "lib" or m.startswith("lib.")]:
         del sys.modules[name]
+
+
+def install():
+    """Make `import lib....` resolve to the REFERENCE.  Both the reference's `lib/` and this repository's drop-in `lib/`
+    are namespace packages (no __init__.py), so whichever root comes first on sys.path provides a module that both have
+    (lib.models.builder, lib.models.MicKey.compute_pose): the reference root goes to the front and cached `lib*` modules
+    are dropped.  uninstall() restores the drop-in."""
+    if not available():
+        raise RuntimeError("reference tree not found at %s" % REF_ROOT)
+    while REF_ROOT in sys.path:
+        sys.path.remove(REF_ROOT)
+    sys.path.insert(0, REF_ROOT)
+    _purge_lib()
+    for name, mod in _stub_modules().items():
+        sys.modules.setdefault(name, mod)
+
+
+def uninstall():
+    while REF_ROOT in sys.path:
+        sys.path.remove(REF_ROOT)
+    _purge_lib()
+
+
+def _stub_modules():
+    out = {}
     if "cv2" not in sys.modules:
-        sys.modules["cv2"] = types.ModuleType("cv2")
+        out["cv2"] = types.ModuleType("cv2")
     if "pytorch_lightning" not in sys.modules:
         pl = types.ModuleType("pytorch_lightning")
         pl.LightningModule = torch.nn.Module
-        sys.modules["pytorch_lightning"] = pl
+        out["pytorch_lightning"] = pl
+    return out
 
 
 def build_reference_model(cfg, state_dict, float16=False):

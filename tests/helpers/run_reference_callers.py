@@ -1,0 +1,95 @@
+"""Run the REFERENCE's own callers -- demo_inference.run_demo_inference (demo_inference.py:79-138) and
+submission.predict / save_submission (submission.py:32-68) -- against the drop-in `lib` overlay of this repository.
+
+Executed as a subprocess by tests/test_reference_callers.py with
+    PYTHONPATH = <this repo>:<reference checkout>      (the overlay of INTEGRATION.md section 1)
+so `lib.models.builder` / `lib.models.MicKey.compute_pose` / `lib.utils.data` resolve HERE and every other module the
+callers import (config.default, lib.datasets.utils, lib.utils.visualization, lib.models.MicKey.modules...training_utils)
+stays the reference's.  Third-party modules absent from this container are stood in for by ref_env_shims.
+
+backend = "hip": the module runs its real forward (needs a GPU).  backend = "oracle": no GPU in the build container, so
+`MickeyRelativePose.forward` is replaced by the CPU oracle FOR THIS TEST PROCESS ONLY -- what is exercised is everything
+around the kernels: yacs config handed to build_model, checkpoint + DINOv2 file loading, float64 intrinsics from
+torch.from_numpy, the keys / shapes / devices the reference's consumers read back from `data`.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_env_shims  # noqa: E402
+
+
+def patch_forward_with_oracle():
+    from mickey_amd import model as M
+    from mickey_amd.synthetic import DINO_PREFIX
+    from oracle import mickey_oracle as O
+
+    def forward(self, data, return_inliers=False):
+        cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
+        cpu["K_color0"], cpu["K_color1"] = cpu["K_color0"].float(), cpu["K_color1"].float()
+        heads = self._sd[DINO_PREFIX + "cls_token"].shape[-1] // 64
+        with torch.no_grad():
+            R, t = O.mickey_forward(self._sd, self.cfg, cpu, return_inliers, heads=heads)
+        for k, v in cpu.items():
+            if k not in ("image0", "image1", "K_color0", "K_color1"):
+                data[k] = v
+        return R, t
+    M.MickeyRelativePose.forward = forward
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workdir", required=True)
+    ap.add_argument("--reference", required=True)
+    ap.add_argument("--backend", default="oracle", choices=["oracle", "hip"])
+    a = ap.parse_args()
+    ref_env_shims.install()
+    import cv2
+    if a.backend == "oracle":
+        patch_forward_with_oracle()
+    os.chdir(a.workdir)
+    out = {}
+
+    # ---- demo_inference.py, its own function, its own argument names
+    import demo_inference
+    import lib.models.builder as builder
+    import lib.utils.visualization as vis
+    out["builder_file"] = os.path.abspath(builder.__file__)
+    out["visualization_file"] = os.path.abspath(vis.__file__)
+    args = argparse.Namespace(im_path_ref=os.path.join(a.workdir, "im0.jpg"), im_path_dst=os.path.join(a.workdir, "im1.jpg"),
+                              intrinsics=os.path.join(a.workdir, "intrinsics.txt"), resize=None,
+                              config=os.path.join(a.workdir, "config.yaml"), checkpoint=os.path.join(a.workdir, "mickey.ckpt"),
+                              generate_3D_vis=False)
+    demo_inference.run_demo_inference(args)
+    out["demo_written"] = cv2.written[:]
+
+    # ---- submission.py: predict() on a two-batch loader with the dataset's extra keys, then its zip writer
+    import submission
+    from lib.models.builder import build_model
+    cfg = demo_inference.cfg
+    model = build_model(cfg, checkpoint=args.checkpoint)
+    g = torch.Generator().manual_seed(3)
+    K = torch.from_numpy(np.array([[300.0, 0, 98.0], [0, 300.0, 91.0], [0, 0, 1.0]]))   # float64, as np.loadtxt gives
+    loader = []
+    for b in range(2):
+        B = 2
+        loader.append({"image0": torch.rand((B, 3, 182, 196), generator=g), "image1": torch.rand((B, 3, 182, 196), generator=g),
+                       "K_color0": K.repeat(B, 1, 1), "K_color1": K.repeat(B, 1, 1), "scene_id": ["s%05d" % (b % 2)] * B,
+                       "pair_names": (["seq0/frame_00000.jpg"] * B, ["seq1/frame_%05d.jpg" % (10 * b + i) for i in range(B)]),
+                       "T_0to1": torch.eye(4).repeat(B, 1, 1)})
+    res = submission.predict(loader, model)
+    zpath = os.path.join(a.workdir, "submission.zip")
+    submission.save_submission(res, zpath)
+    out["scenes"] = {k: [str(p) for p in v] for k, v in res.items()}
+    out["zip"] = zpath
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -124,3 +124,19 @@ def test_planted_pose_generator_is_consistent():
     X = O.backproject(data["kps0"][0, :, i].t()[None], data["depth_kp0"][0, 0, i][None, :, None], data["K_color0"])
     Y = O.backproject(data["kps1"][0, :, j].t()[None], data["depth_kp1"][0, 0, j][None, :, None], data["K_color1"])
     assert float(O.point_dist(X, Y, R, t).max()) < 2e-3
+
+
+def test_intrinsics_rescale_matches_the_reference_formula():
+    """mickey_amd.input_pipeline.correct_intrinsic_scale == reference lib/datasets/utils.py:86-99 (restated in
+    oracle/input_oracle.py; identical when imported from the reference tree where it exists)."""
+    import numpy as np
+    import torch
+    from mickey_amd import input_pipeline as ip
+    from oracle import input_oracle as IO
+    K = torch.tensor([[549.7018, 0.0, 268.6665], [0.0, 549.7018, 351.8357], [0.0, 0.0, 1.0]])
+    for sx, sy in ((1.0, 1.0), (0.5, 0.5), (196 / 540, 182 / 720), (2.0, 1.5)):
+        assert torch.equal(ip.correct_intrinsic_scale(K, sx, sy), IO.correct_intrinsic_scale(K, sx, sy))
+    # oracle's bilinear: identity resize returns the input, and a constant image stays constant
+    img = np.full((7, 9, 3), 37, np.uint8)
+    assert np.array_equal(IO.resize_bilinear(img, 9, 7), img.astype(np.float32))
+    assert np.allclose(IO.resize_bilinear(img, 20, 15), 37.0)

@@ -83,3 +83,31 @@ def test_full_forward_matches_reference(golden, cfg):
     assert rel(data["inliers"], g["inliers"]) < 1e-4
     assert data["inliers_list"][0].shape == g["inliers_list0"].shape
     assert np.array_equal(O.mutual_nn_matches(torch.from_numpy(g["scores"])[:1]).numpy(), g["mnn"])
+
+
+def test_committed_fixtures_reproduce_from_the_reference(tmp_path):
+    """The oracle pin must stay runnable: regenerate every fixture from THE REFERENCE (oracle/make_golden.py, in a
+    subprocess so that the reference's `lib` namespace does not leak into this session) and compare with the committed
+    files.  Skipped where /root/reference does not exist (the GPU box)."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), str(tmp_path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
+    gold = os.path.join(root, "tests", "golden")
+    names = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
+    assert names and sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == names
+    for f in names:
+        a, b = dict(np.load(os.path.join(gold, f))), dict(np.load(os.path.join(tmp_path, f)))
+        assert sorted(a) == sorted(b), f
+        for k in a:
+            if a[k].dtype.kind in "iuUSb":
+                assert np.array_equal(a[k], b[k]), (f, k)          # index sets / text lines: bit-exact
+            else:
+                assert np.allclose(a[k], b[k], rtol=0, atol=0) or rel(b[k], a[k]) < 1e-6, (f, k, rel(b[k], a[k]))
