@@ -22,7 +22,8 @@ ARCH = "gfx950"
 # per-file extra flags.  The attention kernel's softmax is VALU-bound: without NaN-honouring semantics fmaxf needs no
 # canonicalising v_max and folds into v_max3 (-18 % VALU instructions); its inputs are finite by construction.
 EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fassociative-math", "-fno-trapping-math"] +
-               (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []),
+               (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []) +
+               (["-DMK_ATTN_LP_DBG"] if os.environ.get("MK_ATTN_LP_DBG") else []),
                "mk_gemm.hip": (["-DMK_PP64_ABLATIONS"] if os.environ.get("MK_PP64_ABLATIONS") else []) +
                               (["-DMK_GEMM_ABLATIONS"] if os.environ.get("MK_GEMM_ABLATIONS") else [])}
 

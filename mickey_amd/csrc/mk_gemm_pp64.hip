@@ -135,7 +135,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   for (int i = 0; i < WMF; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s go out BETWEEN them (behind MFMA 3, 11, 19, 27), pinned
+  // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s.  Dense operands: a piece is one SALU-addressed instruction and
+  // goes out BETWEEN the MFMAs (behind MFMA 3, 11, 19, 27), pinned.  Conv: every piece needs ~15 VALU instructions of
+  // per-lane address arithmetic (tap shift, border test, zero page), which inside the MFMA stream cost more than they
+  // hide (conv layers 11.7 vs 10.2 ms per step): they are issued behind the MFMAs, as one batch.
   auto mfma32 = [&](const V8* wf, const V8* xf, auto dma, int s) {
     constexpr bool DMA = decltype(dma)::value;
     const Tap t = DMA ? conv_tap(s) : Tap{nullptr, 0, 0, 0, 0};
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     for (int q = 0; q < 32; ++q) {
       const int mi = q >> 2, ni = q & 3;
       acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
-      if (DMA && (q & 7) == 3) {
+      if (DMA && AMODE == A_DENSE && (q & 7) == 3) {
         __builtin_amdgcn_sched_barrier(0);
         dma_a1(s, q >> 3, t);
         __builtin_amdgcn_sched_barrier(0);
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
+    if (DMA && AMODE != A_DENSE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma_a1(s, j, t);
+    }
   };
   auto bar = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

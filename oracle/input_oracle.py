@@ -19,7 +19,7 @@ def resize_bilinear(img, w, h):
     src = img.astype(np.float32)
 
     def axis(n_dst, n_src):
-        f = (np.arange(n_dst, dtype=np.float32) + np.float32(0.5)) * np.float32(n_src / n_dst) - np.float32(0.5)
+        f = (np.arange(n_dst, dtype=np.float32) + np.float32(0.5)) * (np.float32(n_src) / np.float32(n_dst)) - np.float32(0.5)
         i0 = np.floor(f).astype(np.int64)
         fr = (f - i0.astype(np.float32)).astype(np.float32)
         lo = i0 < 0
