@@ -137,18 +137,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s.  Dense operands: a piece is one SALU-addressed instruction and
   // goes out BETWEEN the MFMAs (behind MFMA 3, 11, 19, 27), pinned.  Conv: every piece needs ~15 VALU instructions of
-  // per-lane address arithmetic (tap shift, border test, zero page), which inside the MFMA stream cost more than they
-  // hide (conv layers 11.7 vs 10.2 ms per step): they are issued behind the MFMAs, as one batch.
+  // per-lane address arithmetic (tap shift, border test, zero page), which inside (or right behind) the MFMA stream cost
+  // more than they hide (conv layers 13.6 / 11.9 vs 10.2 ms per step): the conv pieces of stage kt+1 go out in the
+  // wave-row's NON-MFMA slot instead (first fragment slot of stage kt, next to the W pieces), where the other wave-row
+  // owns the matrix pipe and this row's VALU is idle.
+  constexpr bool A_IN_MFMA_SLOT = AMODE == A_DENSE;
   auto mfma32 = [&](const V8* wf, const V8* xf, auto dma, int s) {
-    constexpr bool DMA = decltype(dma)::value;
-    const Tap t = DMA ? conv_tap(s) : Tap{nullptr, 0, 0, 0, 0};
+    constexpr bool DMA = decltype(dma)::value && A_IN_MFMA_SLOT;
+    const Tap t = Tap{nullptr, 0, 0, 0, 0};
     __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
       const int mi = q >> 2, ni = q & 3;
       acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
-      if (DMA && AMODE == A_DENSE && (q & 7) == 3) {
+      if (DMA && (q & 7) == 3) {
         __builtin_amdgcn_sched_barrier(0);
         dma_a1(s, q >> 3, t);
         __builtin_amdgcn_sched_barrier(0);
@@ -156,10 +159,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
-    if (DMA && AMODE != A_DENSE) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dma_a1(s, j, t);
-    }
   };
   auto bar = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -173,14 +172,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   auto stage0 = [&](int kt, auto next1, auto next2) {
     bar();   // slot 4kt
     load_frags(wf, xf, kt & 1, 0);
-    if constexpr (decltype(next1)::value) dma_w(kt + 1);
+    if constexpr (decltype(next1)::value) {
+      dma_w(kt + 1);
+      if constexpr (!A_IN_MFMA_SLOT) dma_a(kt + 1);
+    }
     bar();                      // slot 4kt+1
     mfma32(wf, xf, No{}, 0);
     bar();                      // slot 4kt+2
     load_frags(wf, xf, kt & 1, 1);
     bar();                      // slot 4kt+3
     mfma32(wf, xf, next2, kt + 2);
-    if constexpr (decltype(next2)::value)
+    if constexpr (decltype(next2)::value && A_IN_MFMA_SLOT)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,7 +190,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   auto stage1 = [&](int kt, auto next1, auto next2) {
     bar();                      // slot 4kt+1
     load_frags(wf, xf, kt & 1, 0);
-    if constexpr (decltype(next1)::value) dma_w(kt + 1);
+    if constexpr (decltype(next1)::value) {
+      dma_w(kt + 1);
+      if constexpr (!A_IN_MFMA_SLOT) dma_a(kt + 1);
+    }
     bar();                      // slot 4kt+2
     mfma32(wf, xf, No{}, 0);
     bar();                      // slot 4kt+3
@@ -201,8 +206,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // prologue: stage 0 (own A half + W share) and the own A half of stage 1 (nk >= 2, see launch())
   dma_a(0);
   dma_w(0);
-  dma_a(1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (A_IN_MFMA_SLOT) {
+    dma_a(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if (wm == 0) {
     for (int kt = 0; kt < nk - 2; ++kt) stage0(kt, Yes{}, Yes{});
     stage0(nk - 2, Yes{}, No{});
