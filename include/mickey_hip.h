@@ -249,6 +249,33 @@ int mk_refine_pose(const float* X, const float* Y, const float* Rh, const float*
 /* If *invalid != 0: zero R, t, conf for the whole batch (reference :338-342). */
 int mk_pose_finalize(float* R, float* t, float* conf, const int* invalid, int B, mk_stream_t stream);
 
+/* ---- training-time RANSAC -----------------------------------------------------------------------
+ * The no-grad core of MetricPoseLoss.single_iteration_RANSAC (reference lib/models/MicKey/modules/loss/loss_class.py:141-184):
+ * for every sampled match set r in [0, nsets) (S matches: X, Y [nsets, S, 3], wts [nsets, S]) and every hypothesis
+ * h in [0, it_ransac): draw num_corr matches without replacement ~ wts (:148; exponential race; noise = NULL: Philox
+ * keyed by (seed, offset, set_base * it_ransac + r * it_ransac + h); noise != NULL: fp32 Exp(1) [nsets*it_ransac, S]
+ * injected; idx_in != NULL: int32 [nsets*it_ransac, num_corr] indices injected), then <= num_ref refinement rounds
+ * {masked weighted Procrustes over the current set (loss/solvers.py:13-26,45-52) -> matches within th_ref
+ * (training_utils.py:71-75) -> accept iff their number grew} exactly as the reference's masked tensor updates do (:152-184).
+ *   final_mask float32 [nsets*it_ransac, S]  `inliers_final`: 0/1, the set that produced the last accepted pose -- the
+ *                                            weights of the differentiable Procrustes the caller runs next (:187)
+ *   idx_out    int32 [nsets*it_ransac, num_corr]  the drawn matches, in draw order (descending race key)
+ *   rounds     int32 [nsets*it_ransac]       accepted refinement rounds
+ * S <= 1024, 3 <= num_corr <= S. */
+int mk_train_ransac_masks(const float* X, const float* Y, const float* wts, const float* noise, const int* idx_in,
+                          unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev,
+                          float th_ref, int num_ref, int num_corr, float* final_mask, int* idx_out, int* rounds, int nsets,
+                          int it_ransac, int S, long long set_base, mk_stream_t stream);
+
+/* REINFORCE bookkeeping of the same function (loss_class.py:251-261, a python loop over B*it_matches rows in the
+ * reference): for row = b*it_matches + r, r ascending, and every sampled cell c = idx[row, s]:
+ *   gradients[b, c] += loss_value[row];  gradients_b[b, c] += 1
+ * fp32, rows applied in the reference's order (bit-identical sums).  Cells of one row must be distinct (they come from
+ * sampling without replacement).  idx int32 [B*it_matches, S]; gradients, gradients_b float32 [B, ncell], zeroed by the
+ * caller. */
+int mk_reinforce_scatter(const int* idx, const float* loss_value, float* gradients, float* gradients_b, int B,
+                         int it_matches, int S, long long ncell, mk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mk_ransac_hypotheses": ("i", "pppppuupfppppiiilp"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),
     "mk_pose_finalize": ("i", "ppppip"),
+    "mk_train_ransac_masks": ("i", "pppppuupfiipppiiilp"),
+    "mk_reinforce_scatter": ("i", "ppppiiilp"),
 }
 
 # development knobs (include/mickey_hip_dev.h): process-wide schedule selectors for benchmarks / tests, never called by

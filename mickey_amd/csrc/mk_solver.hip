@@ -694,6 +694,174 @@ __global__ __launch_bounds__(RT) void refine_kernel(const float* __restrict__ X,
   if (tid == 0) { conf[b] = (float)ctot; best[b] = hb; rounds[b] = nround; }
 }
 
+// ---- training-time RANSAC (reference loss/loss_class.py:141-184) -------------------------------
+// One workgroup per sampled match set (row r: S matches X, Y, w staged in LDS once), one wave per hypothesis.  A hypothesis
+// draws NUM_CORR matches without replacement ~ w (exponential race: top-NUM_CORR of w / Exp(1), Philox in registers or
+// injected noise / indices), then runs the reference's refinement state machine:
+//     cur = sample, fin = sample, pre = NUM_CORR
+//     repeat NUM_REF_STEPS: (R, t) = masked Procrustes(cur); ref = {|R x + t - y| <= th}; stop unless |ref| > pre;
+//                           pre = |ref|, fin = cur, cur = ref
+// and emits fin as a 0/1 float mask [S] -- the input of the differentiable Procrustes the loss is built on.  Match j of a
+// row lives in lane j % 64, slot j / 64 (S <= 1024): the three sets are 16-bit masks per lane, no memory traffic.
+constexpr int TR_SLOTS = 16;
+
+__global__ __launch_bounds__(256) void train_refine_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                           const float* __restrict__ wts, const float* __restrict__ noise,
+                                                           const int* __restrict__ idx_in, unsigned k0, unsigned k1,
+                                                           unsigned off_lo, unsigned off_hi,
+                                                           const unsigned long long* __restrict__ offp, float th_ref,
+                                                           int num_ref, int nc, float* __restrict__ fin_mask,
+                                                           int* __restrict__ idx_out, int* __restrict__ rounds_out,
+                                                           int it_ransac, int S, long long set_base) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // X[S*3] | Y[S*3] | w[S]
+  add_device_offset(off_lo, off_hi, offp);
+  float* sX = lds;
+  float* sY = lds + (size_t)S * 3;
+  float* sW = lds + (size_t)S * 6;
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < S * 3; i += 256) {
+    sX[i] = X[(long long)r * S * 3 + i];
+    sY[i] = Y[(long long)r * S * 3 + i];
+  }
+  for (int i = threadIdx.x; i < S; i += 256) sW[i] = wts[(long long)r * S + i];
+  __syncthreads();
+  const int nq = (S + 63) >> 6;
+  for (int h = wave; h < it_ransac; h += 4) {
+    const long long hyp = (long long)r * it_ransac + h;
+    unsigned cur = 0;
+    if (idx_in) {
+      for (int c = 0; c < nc; ++c) {
+        const int j = idx_in[hyp * nc + c];
+        if ((j & 63) == lane) cur |= 1u << (j >> 6);
+        if (lane == 0) idx_out[hyp * nc + c] = j;
+      }
+    } else {
+      float key[TR_SLOTS];
+#pragma unroll
+      for (int q4 = 0; q4 < TR_SLOTS / 4; ++q4) {
+        float e[4] = {1.f, 1.f, 1.f, 1.f};
+        if (q4 * 4 < nq) {
+          if (noise) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = (q4 * 4 + u) * 64 + lane;
+              if (j < S) e[u] = noise[hyp * S + j];
+            }
+          } else {
+            const long long gh = hyp + set_base * it_ransac;   // GLOBAL hypothesis index (sharding-invariant draws)
+            const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(q4 * 64 + lane), (unsigned)gh, (unsigned)(gh >> 32) ^ off_hi ^ 0x2545f491u, off_lo});
+            e[0] = exp1(rnd.x); e[1] = exp1(rnd.y); e[2] = exp1(rnd.z); e[3] = exp1(rnd.w);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = (q4 * 4 + u) * 64 + lane;
+          key[q4 * 4 + u] = j < S ? sW[j] / e[u] : -1.f;
+        }
+      }
+      for (int c = 0; c < nc; ++c) {
+        float v = -1.f;
+        int ix = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < TR_SLOTS; ++q)
+          if (!((cur >> q) & 1u) && key[q] > v) { v = key[q]; ix = q * 64 + lane; }   // ascending j within a lane: first wins ties
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float v2 = __shfl_xor(v, o, 64);
+          const int i2 = __shfl_xor(ix, o, 64);
+          if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        }
+        if (ix != 0x7fffffff && (ix & 63) == lane) cur |= 1u << (ix >> 6);
+        if (lane == 0) idx_out[hyp * nc + c] = ix == 0x7fffffff ? 0 : ix;
+      }
+    }
+    unsigned fin = cur;
+    int pre = nc, nround = 0;
+    for (int it = 0; it < num_ref; ++it) {
+      // masked Procrustes over cur: centroids with w / (sum|w| + 1e-16), covariance with the RAW 0/1 mask (solvers.py:14-26)
+      double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+      int cl = 0;
+#pragma unroll
+      for (int q = 0; q < TR_SLOTS; ++q)
+        if ((cur >> q) & 1u) {
+          const int j = q * 64 + lane;
+          ++cl;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { sa[a] += sX[j * 3 + a]; sb[a] += sY[j * 3 + a]; }
+        }
+      const double C = wave_sum_d((double)cl);
+      const float wn = 1.0f / ((float)C + 1e-16f);
+      double am[3], bm[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        am[a] = wave_sum_d(sa[a]) * (double)wn;
+        bm[a] = wave_sum_d(sb[a]) * (double)wn;
+      }
+      double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < TR_SLOTS; ++q)
+        if ((cur >> q) & 1u) {
+          const int j = q * 64 + lane;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hl[a * 3 + c] += ((double)sX[j * 3 + a] - am[a]) * ((double)sY[j * 3 + c] - bm[c]);
+        }
+      double H[9], Rd[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) H[i] = wave_sum_d(hl[i]);
+      kabsch_rotation(H, Rd);
+      float Rf[9], tf[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) tf[a] = (float)bm[a] - ((float)am[0] * Rf[a * 3 + 0] + (float)am[1] * Rf[a * 3 + 1] + (float)am[2] * Rf[a * 3 + 2]);
+      unsigned ref = 0;
+      int rl = 0;
+#pragma unroll
+      for (int q = 0; q < TR_SLOTS; ++q) {
+        const int j = q * 64 + lane;
+        if (j < S && th_ref - pt_dist(Rf, tf, sX + j * 3, sY + j * 3) >= 0.f) { ref |= 1u << q; ++rl; }
+      }
+      const int cnt = (int)wave_sum((float)rl);
+      if (!(cnt > pre)) break;   // wave-uniform
+      pre = cnt;
+      fin = cur;
+      cur = ref;
+      ++nround;
+    }
+#pragma unroll
+    for (int q = 0; q < TR_SLOTS; ++q) {
+      const int j = q * 64 + lane;
+      if (j < S) fin_mask[hyp * S + j] = (fin >> q) & 1u ? 1.f : 0.f;
+    }
+    if (lane == 0) rounds_out[hyp] = nround;
+  }
+}
+
+// REINFORCE bookkeeping (loss_class.py:251-261): gradients[b, c] += loss_value[row], gradients_b[b, c] += 1 for the S
+// sampled cells c of every row of pair b, ROW AFTER ROW like the reference's python loop (a cell drawn by several rows
+// receives its fp32 additions in the same order: bit-identical sums).  Cells within a row are distinct (sampling without
+// replacement), so a row is a plain read-modify-write; one workgroup per pair, a barrier between rows.
+__global__ __launch_bounds__(512) void reinforce_scatter_kernel(const int* __restrict__ idx, const float* __restrict__ loss_value,
+                                                                float* __restrict__ grads, float* __restrict__ grads_b,
+                                                                int it_matches, int S, long long ncell) {
+  const int b = blockIdx.x;
+  float* g = grads + (long long)b * ncell;
+  float* gb = grads_b + (long long)b * ncell;
+  for (int r = 0; r < it_matches; ++r) {
+    const long long row = (long long)b * it_matches + r;
+    const float lv = loss_value[row];
+    for (int s = threadIdx.x; s < S; s += 512) {
+      const int c = idx[row * S + s];
+      g[c] += lv;
+      gb[c] += 1.0f;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void finalize_kernel(float* R, float* t, float* conf, const int* invalid, int B) {
   if (*invalid == 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -819,6 +987,31 @@ int mk_refine_pose(const float* X, const float* Y, const float* Rh, const float*
 int mk_pose_finalize(float* R, float* t, float* conf, const int* invalid, int B, mk_stream_t stream) {
   MK_CHECK_ARG(R && t && conf && invalid && B > 0, "mk_pose_finalize: bad args");
   hipLaunchKernelGGL(finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, t, conf, invalid, B);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_train_ransac_masks(const float* X, const float* Y, const float* wts, const float* noise, const int* idx_in,
+                          unsigned long long seed, unsigned long long offset, const unsigned long long* offset_dev, float th_ref,
+                          int num_ref, int num_corr, float* final_mask, int* idx_out, int* rounds, int nsets, int it_ransac,
+                          int S, long long set_base, mk_stream_t stream) {
+  MK_CHECK_ARG(X && Y && wts && final_mask && idx_out && rounds, "mk_train_ransac_masks: null pointer");
+  MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && S > 0 && S <= 64 * TR_SLOTS && num_corr >= 3 && num_corr <= S && num_ref >= 0,
+               "mk_train_ransac_masks: bad sizes (3 <= num_corr <= S <= %d)", 64 * TR_SLOTS);
+  const size_t lds = (size_t)S * 7 * sizeof(float);
+  hipLaunchKernelGGL(train_refine_kernel, dim3(nsets), dim3(256), lds, (hipStream_t)stream, X, Y, wts, noise, idx_in,
+                     (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), offset_dev, th_ref,
+                     num_ref, num_corr, final_mask, idx_out, rounds, it_ransac, S, set_base);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_reinforce_scatter(const int* idx, const float* loss_value, float* gradients, float* gradients_b, int B, int it_matches,
+                         int S, long long ncell, mk_stream_t stream) {
+  MK_CHECK_ARG(idx && loss_value && gradients && gradients_b, "mk_reinforce_scatter: null pointer");
+  MK_CHECK_ARG(B > 0 && it_matches > 0 && S > 0 && ncell > 0 && ncell < (1LL << 31), "mk_reinforce_scatter: bad sizes");
+  hipLaunchKernelGGL(reinforce_scatter_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, idx, loss_value, gradients,
+                     gradients_b, it_matches, S, ncell);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

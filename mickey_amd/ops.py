@@ -254,6 +254,37 @@ def ransac_hypotheses(X, Y, wts, it_ransac, th_soft, noise3=None, idx3_in=None, 
     return Rh, th, score, idx3
 
 
+def train_ransac_masks(X, Y, wts, it_ransac, th_ref, num_ref, num_corr, noise=None, idx_in=None, seed=0, offset=0,
+                       offset_dev=None, set_base=0):
+    """Training-time hypotheses + refinement (reference loss_class.py:141-184): X, Y [nsets, S, 3], wts [nsets, S] ->
+    (inliers_final fp32 [nsets*it_ransac, S], drawn indices int32 [nsets*it_ransac, num_corr], rounds int32)."""
+    X, Y, wts, noise, idx_in = _c(X, Y, wts, noise, idx_in)
+    _chk(X, torch.float32)
+    nsets, S, _ = X.shape
+    dev = X.device
+    nh = nsets * it_ransac
+    if idx_in is not None:
+        idx_in = idx_in.to(torch.int32)
+    mask = torch.empty((nh, S), device=dev, dtype=torch.float32)
+    idx = torch.empty((nh, num_corr), device=dev, dtype=torch.int32)
+    rounds = torch.empty((nh,), device=dev, dtype=torch.int32)
+    call("mk_train_ransac_masks", ptr(X), ptr(Y), ptr(wts), ptr(noise), ptr(idx_in), int(seed), int(offset), ptr(offset_dev),
+         float(th_ref), int(num_ref), int(num_corr), ptr(mask), ptr(idx), ptr(rounds), nsets, it_ransac, S, int(set_base),
+         stream())
+    return mask, idx, rounds
+
+
+def reinforce_scatter(idx, loss_value, B, it_matches, ncell):
+    """REINFORCE bookkeeping (reference loss_class.py:251-261): idx int32 [B*it_matches, S], loss_value fp32 [B*it_matches]
+    -> (gradients, gradients_b) fp32 [B, ncell]."""
+    idx, loss_value = _c(idx.to(torch.int32), loss_value.to(torch.float32))
+    S = idx.shape[1]
+    dev = idx.device
+    grads = torch.zeros((B, ncell), device=dev, dtype=torch.float32)
+    grads_b = torch.zeros((B, ncell), device=dev, dtype=torch.float32)
+    call("mk_reinforce_scatter", ptr(idx), ptr(loss_value), ptr(grads), ptr(grads_b), B, it_matches, S, ncell, stream())
+    return grads, grads_b
+
 def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers, invalid=None):
     X, Y, Rh, th, score = _c(X, Y, Rh, th, score)
     k = X.shape[1]
