@@ -86,8 +86,8 @@ def test_full_forward_matches_reference(golden, cfg):
 
 
 def test_committed_fixtures_reproduce_from_the_reference(tmp_path):
-    """The oracle pin must stay runnable: regenerate every fixture from THE REFERENCE (oracle/make_golden.py, in a
-    subprocess so that the reference's `lib` namespace does not leak into this session) and compare with the committed
+    """The oracle pin must stay runnable: regenerate every fixture from THE REFERENCE (oracle/make_golden.py and
+    oracle/make_golden_train.py, in a subprocess so that the reference's `lib` namespace does not leak into this session) and compare with the committed
     files.  Skipped where /root/reference does not exist (the GPU box)."""
     import os
     import subprocess
@@ -97,9 +97,10 @@ def test_committed_fixtures_reproduce_from_the_reference(tmp_path):
     if not ref_shim.available():
         pytest.skip("reference tree not present")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), str(tmp_path)], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:]
+    for script in ("make_golden.py", "make_golden_train.py"):   # hot path; training-time RANSAC (row N3)
+        r = subprocess.run([sys.executable, os.path.join(root, "oracle", script), str(tmp_path)], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=root)
+        assert r.returncode == 0, r.stdout[-3000:]
     gold = os.path.join(root, "tests", "golden")
     names = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
     assert names and sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == names
