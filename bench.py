@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
-TRAFFIC_SOURCE = "profiles/r01_pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json"
 
 
 def pmc_traffic_bytes(batch):
@@ -223,8 +223,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short fp16 run reported under 'alt'")
-    ap.add_argument("--include-h2d", action="store_true",
-                    help="also report the PCIe-inclusive rate: uint8 frames from pinned host memory through the input pipeline")
+    ap.add_argument("--include-h2d", action="store_true", default=True,
+                    help="also report the PCIe-inclusive rate under 'pcie_inclusive' (default at N=1): uint8 frames from host "
+                         "memory through the input pipeline (pinned ring, H2D, resize kernel) into the forward; never `value`")
+    ap.add_argument("--no-h2d", dest="include_h2d", action="store_false", help="skip the PCIe-inclusive leg")
     ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
     ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
