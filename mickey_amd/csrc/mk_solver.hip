@@ -179,6 +179,126 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
   }
 }
 
+// ---- Philox collect pass with a 6-bit pre-filter ---------------------------------------------------------------------
+// The scan above draws one full uniform per (row, cell): 5 Philox calls per cell for 20 rows, 2.4 G draws per 32-pair
+// step, of which one in ~1400 becomes a candidate.  A key p/e reaches the threshold T only if e = -ln(u) <= p/T; for a
+// cell with p < 0.0155 T that needs u > 1 - 2^-6, i.e. the top 6 bits of the 24-bit uniform all ones.  So:
+//   stage 1  one Philox call per cell yields the TOP 6 bits of the uniforms of 20 rows (5 x 6 bits per 32-bit word); only
+//            (cell, row) pairs whose 6 bits are all ones (1 in 64) are queued in LDS;
+//   stage 2  the queue is processed densely: one Philox call per queued pair, keyed by (cell, row), yields the LOW 18
+//            bits; u = (top6 << 18 | low18 + 0.5) 2^-24, key = p / -ln(u), candidate test, append (as in the scan).
+// The joint distribution is that of independent 24-bit uniforms per (row, cell) -- the sampler is unchanged, the RNG work
+// drops from 5 to ~1.3 Philox calls per cell.  Cells with p >= 0.0155 T (a few thousand per pair) take stage 2 for all
+// their rows.  Counter layout: z = (pair + pair_base) * 512 + {256 + row / 20 (stage 1) | row (stage 2)}.
+constexpr int PF_CPT = 4;         // cells per thread per iteration
+constexpr int PF_QCAP = 2048;     // queued (cell, row) pairs per iteration (expected 320 + 20 per large-p cell)
+constexpr int PF_LCAP = 128;      // LDS candidate slots per row and block (expected ~20)
+constexpr int PF_MAXROWS = 48;   // LDS: rows x 1 KiB of candidates + 8 KiB queue <= 56 KiB
+
+__global__ __launch_bounds__(256) void exprace_prefilter_kernel(const float* __restrict__ p, unsigned k0, unsigned k1,
+                                                                unsigned off_lo, unsigned off_hi,
+                                                                const unsigned long long* __restrict__ offp, TopkWork w,
+                                                                int rows_per_pair, long long ncell) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pf_smem[];
+  unsigned long long* lbuf = (unsigned long long*)pf_smem;                       // [rows][PF_LCAP]
+  unsigned* queue = (unsigned*)(pf_smem + (size_t)rows_per_pair * PF_LCAP * 8);   // [PF_QCAP]
+  __shared__ unsigned lcount[PF_MAXROWS], lbase[PF_MAXROWS];
+  __shared__ unsigned qcount;
+  add_device_offset(off_lo, off_hi, offp);
+  const int b = blockIdx.y;
+  const long long per = (ncell + gridDim.x - 1) / gridDim.x;
+  const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
+  const unsigned zb = (unsigned)(b + w.pair_base) * 512u;
+  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (exprace_athresh_kernel)
+  const float T = __uint_as_float((unsigned)thr0 << 20);
+  const float pfast = 0.0155f * T;                     // -ln(1 - 2^-6) = 0.015748: margin for the 1-ulp log / rcp
+  const float pnever = 2.9e-8f * T;                    // smallest e: -ln(1 - 2^-25) = 2.98e-8
+  if (threadIdx.x < rows_per_pair) lcount[threadIdx.x] = 0;
+  if (threadIdx.x == 0) qcount = 0;
+  __syncthreads();
+  const float* pb = p + (long long)b * ncell;
+
+  auto finish = [&](unsigned cl, int r, unsigned top6) {   // stage 2 for one (cell, row)
+    const long long c = c0 + cl;
+    const float pv = pb[c];
+    const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, off_hi, zb + (unsigned)r, off_lo});
+    const unsigned r24 = (top6 << 18) | (rnd.x >> 14);
+    const float key = race_key(pv, r24 << 8);
+    const unsigned bits = __float_as_uint(key);
+    if ((int)((bits & 0x7fffffffu) >> 20) < thr0) return;
+    const unsigned long long item = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+    const unsigned ls = atomicAdd(&lcount[r], 1u);
+    if (ls < (unsigned)PF_LCAP) {
+      lbuf[r * PF_LCAP + ls] = item;
+    } else {
+      const int row = b * rows_per_pair + r;
+      const unsigned slot = atomicAdd(&w.ncand[row], 1u);
+      if (slot < CAND_MAX) w.cand[(long long)row * CAND_MAX + slot] = item;
+    }
+  };
+
+  for (long long base = c0; base < c1; base += 256 * PF_CPT) {
+#pragma unroll
+    for (int u = 0; u < PF_CPT; ++u) {
+      const long long c = base + u * 256 + threadIdx.x;
+      if (c >= c1) continue;
+      const float pv = pb[c];
+      if (!(pv > pnever) || isinf(pv)) continue;   // key <= p / e_min < T for every possible draw (and p <= 0)
+      const unsigned cl = (unsigned)(c - c0);
+      const bool fast = pv < pfast;
+      for (int rc = 0; rc * 20 < rows_per_pair; ++rc) {
+        const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, off_hi, zb + 256u + (unsigned)rc, off_lo});
+        const unsigned wd[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+        // 20-bit mask of the rows to queue: all of them for a large-p cell, otherwise those whose 6-bit field is all ones
+        // (bit 0 of each field of ~x OR-folded over the field is 0 exactly then) -- ~12 ops per word instead of a
+        // compare + branch per row
+        unsigned mask = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const unsigned y = ~wd[v];
+          const unsigned z = (y | (y >> 1) | (y >> 2) | (y >> 3) | (y >> 4) | (y >> 5)) & 0x01041041u;   // 1 = field not all ones
+          const unsigned pass = ~z & 0x01041041u;
+          const unsigned m5 = (pass & 1u) | ((pass >> 5) & 2u) | ((pass >> 10) & 4u) | ((pass >> 15) & 8u) | ((pass >> 20) & 16u);
+          mask |= m5 << (5 * v);
+        }
+        const int nr = min(20, rows_per_pair - rc * 20);
+        if (!fast) mask = 0xfffffu;
+        mask &= (1u << nr) - 1u;
+        while (mask) {
+          const int q = __builtin_ctz(mask);
+          mask &= mask - 1u;
+          const unsigned top6 = (wd[q / 5] >> (6 * (q % 5))) & 63u;
+          const int r = rc * 20 + q;
+          const unsigned pos = atomicAdd(&qcount, 1u);
+          if (pos < (unsigned)PF_QCAP) queue[pos] = cl | ((unsigned)r << 16) | (top6 << 24);
+          else finish(cl, r, top6);   // queue full (many large-p cells in one iteration): do it in place
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned n = min(qcount, (unsigned)PF_QCAP);
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+      const unsigned it = queue[i];
+      finish(it & 0xffffu, (int)((it >> 16) & 0xffu), it >> 24);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+  }
+  if (threadIdx.x < rows_per_pair) {
+    const int r = threadIdx.x;
+    const unsigned nloc = min(lcount[r], (unsigned)PF_LCAP);
+    lbase[r] = nloc ? atomicAdd(&w.ncand[b * rows_per_pair + r], nloc) : 0u;
+  }
+  __syncthreads();
+  for (int r = 0; r < rows_per_pair; ++r) {
+    const unsigned nloc = min(lcount[r], (unsigned)PF_LCAP), bs = lbase[r];
+    const long long row = (long long)b * rows_per_pair + r;
+    for (unsigned i = threadIdx.x; i < nloc; i += 256)
+      if (bs + i < (unsigned)CAND_MAX) w.cand[row * CAND_MAX + bs + i] = lbuf[r * PF_LCAP + i];
+  }
+}
+
 // one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
 __global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k) {
   __shared__ unsigned part[256];
@@ -926,7 +1046,16 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(exprace_athresh_kernel, dim3(B), dim3(256), 0, st, w, rows_per_pair, 1.25f * (float)k);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+  // the block-local cell index must fit 16 bits of a queue entry: more cell blocks for very large matrices
+  int pcb = cb;
+  while ((ncell + pcb - 1) / pcb > 65536) pcb *= 2;
+  if (!noise && rows_per_pair <= PF_MAXROWS) {
+    const size_t lds = (size_t)rows_per_pair * PF_LCAP * 8 + (size_t)PF_QCAP * 4;
+    hipLaunchKernelGGL(exprace_prefilter_kernel, dim3(pcb, B), dim3(256), lds, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair,
+                       ncell);
+  } else {
+    hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+  }
   MK_CHECK_LAUNCH();
   // exact fallback (runs only if a row came up short: never observed, kept for adversarial inputs / injected noise)
   hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k);

@@ -1,8 +1,7 @@
 #!/bin/bash
-# One GPU visit (rewritten per experiment during development).
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_mapfree_eval_gpu.py tests/test_train_ransac_gpu.py -q -x -m gpu 2>&1 | tail -8
-timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -8 > gpurun_out/r2_pytest_gpu.txt
-cat gpurun_out/r2_pytest_gpu.txt
-timeout 600 python tools/bench_train_ransac.py 2>&1 | tail -1 > gpurun_out/r2_bench_train_ransac.json
-cat gpurun_out/r2_bench_train_ransac.json
+timeout 900 python -m pytest tests/test_solver_gpu.py tests/test_bench_config_gpu.py -q -x -m gpu 2>&1 | tail -4
+timeout 600 python -m pytest tests/test_model_gpu.py -q -x -m gpu -k "planted or determinism or graph" 2>&1 | tail -3
+timeout 300 python bench.py --no-cpu-baseline --no-alt --no-h2d 2>&1 | tail -1 > gpurun_out/r2_bench_sampler.json; python -c "
+import json
+d=json.load(open('gpurun_out/r2_bench_sampler.json')); print(d['value'], d['ms_per_step']); [print(s['stage'], round(s['ms_per_step'],2), s.get('achieved')) for s in d['roofline']['stages']]"
