@@ -125,27 +125,32 @@ __device__ __forceinline__ f32x16 corr_regs(const float (&a)[CMAX / 2], const fl
   return acc;
 }
 
-// pass 1.  grid (row blocks of 128, NCHUNK, B*2), one wave per 32 rows: side 0 -> rows of S, side 1 -> rows of S^T.
-// part[((b*2+side)*NCHUNK + chunk)*nmax + row][2] = (max2, sum 2^(v2 - max2)) over the chunk's columns
+// pass 1.  grid (row blocks of 128, NCHUNK, B), one wave per 32 rows and one chunk of columns.  ONE correlation serves
+// both softmax directions (round 1 ran it twice, once for S and once for S^T):
+//   * rows of S: per-lane online (max, sum) over the columns this lane sees, merged across the 32 lanes at the end;
+//     partr[((b*NCHUNK + chunk)*n0 + row)][2]
+//   * columns of S: per tile, (max, sum) of this lane's column over the wave's 32 rows (16 in-lane values + one exchange
+//     with lane ^ 32); every (row block, column) pair is produced by exactly one wave: partc[((b*nrb + rb)*n1 + j)][2]
+//   * v2 = S / T * log2(e) itself is stored (vbuf [B, n0, n1]): pass 2 becomes an element-wise kernel instead of a second
+//     correlation (the fp32 matrix pipe is the bound of this stage: 64 MFMAs x 64 cycles per 32 x 32 tile).
 // amdgpu_waves_per_eu(2, 2): without it the scheduler chases occupancy, keeps ONE operand register and emits
 // load -> s_waitcnt vmcnt(0) -> MFMA 64 times per tile (64 serial memory round trips, measured 32 us per tile)
 template <bool FULLC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lse_partial_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
-                                                          float scale2, float* __restrict__ part, int C, int n0, int n1,
-                                                          int nmax, int gx, int nunits) {
-  int bx, by, unit;
-  if (!decode_unit_grid(gx, NCHUNK, nunits, bx, by, unit)) return;
-  const int b = unit >> 1, side = unit & 1;
-  const int nA = side ? n1 : n0, nB = side ? n0 : n1;
-  const float* dA = (side ? dsc1 + (long long)b * C * n1 : dsc0 + (long long)b * C * n0);
-  const float* dB = (side ? dsc0 + (long long)b * C * n0 : dsc1 + (long long)b * C * n1);
+                                                          float scale2, float* __restrict__ partr, float* __restrict__ partc,
+                                                          float* __restrict__ vbuf, int C, int n0, int n1, int nrb, int gx,
+                                                          int nunits) {
+  int bx, by, b;
+  if (!decode_unit_grid(gx, NCHUNK, nunits, bx, by, b)) return;
+  const float* dA = dsc0 + (long long)b * C * n0;
+  const float* dB = dsc1 + (long long)b * C * n1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int i0 = (bx * 4 + wave) * RT;
-  if (i0 >= nA) return;
+  const int rb = bx * 4 + wave, i0 = rb * RT;
+  if (i0 >= n0) return;
   float a[CMAX / 2], bq[CMAX / 2];
-  load_operand<FULLC>(a, dA, C, nA, i0 + l31, hi);
-  const int ntB = (nB + RT - 1) / RT;
+  load_operand<FULLC>(a, dA, C, n0, i0 + l31, hi);
+  const int ntB = (n1 + RT - 1) / RT;
   const int per = (ntB + NCHUNK - 1) / NCHUNK;
   const int jt0 = by * per, jt1 = min(ntB, jt0 + per);
   float rm[16], rs[16];
@@ -153,17 +158,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int r = 0; r < 16; ++r) { rm[r] = -1e30f; rs[r] = 0.f; }
   for (int jt = jt0; jt < jt1; ++jt) {
     const int j = jt * RT + l31;
-    load_operand<FULLC>(bq, dB, C, nB, j, hi);
+    load_operand<FULLC>(bq, dB, C, n1, j, hi);
     const f32x16 acc = corr_regs<FULLC>(a, bq, C);
     MK_LOADS_THEN_MFMAS();
-    if (j < nB) {
+    float v[16];
+    float cm = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      v[r] = acc[r] * scale2;
+      if (i < n0) cm = fmaxf(cm, v[r]);
+    }
+    if (j < n1) {
+      float cs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[r] * scale2;
-        const float M = fmaxf(rm[r], v);
-        rs[r] = rs[r] * __builtin_amdgcn_exp2f(rm[r] - M) + __builtin_amdgcn_exp2f(v - M);
+        const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float M = fmaxf(rm[r], v[r]);
+        rs[r] = rs[r] * __builtin_amdgcn_exp2f(rm[r] - M) + __builtin_amdgcn_exp2f(v[r] - M);
         rm[r] = M;
+        if (i < n0) {
+          cs += __builtin_amdgcn_exp2f(v[r] - cm);
+          vbuf[((long long)b * n0 + i) * n1 + j] = v[r];
+        }
       }
+      // the other 16 rows of this column live in lane ^ 32
+      const float m2 = __shfl_xor(cm, 32, 64), s2 = __shfl_xor(cs, 32, 64);
+      lse2_merge(cm, cs, m2, s2);
+      if (hi == 0) {
+        float* o = partc + (((long long)b * nrb + rb) * n1 + j) * 2;
+        o[0] = cm;
+        o[1] = cs;
+      }
+    } else {
+      (void)__shfl_xor(cm, 32, 64);   // keep the exchange wave-uniform
+      (void)__shfl_xor(cm, 32, 64);
     }
   }
   // combine the 32 lanes that share rows (same hi)
@@ -179,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (row < nA) {
-        float* o = part + ((((long long)b * 2 + side) * NCHUNK + by) * nmax + row) * 2;
+      if (row < n0) {
+        float* o = partr + (((long long)b * NCHUNK + by) * n0 + row) * 2;
         o[0] = rm[r];
         o[1] = rs[r];
       }
@@ -188,71 +217,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-// merge the chunk partials (+ the dustbin term): lse2[(b*2+side)*nmax + row] = log2 sum 2^v2.  grid (nmax/256, 2, B)
-__global__ __launch_bounds__(256) void lse_final_kernel(const float* __restrict__ part, float* __restrict__ lse2, int use_dustbin,
-                                                        float beta2, int n0, int n1, int nmax) {
-  const int row = blockIdx.x * 256 + threadIdx.x, side = blockIdx.y, b = blockIdx.z;
-  if (row >= (side ? n1 : n0)) return;
-  const long long bs = (long long)b * 2 + side;
+// merge the partials (+ the dustbin term): lse2[(b*2+side)*nmax + idx] = log2 sum 2^v2.  grid (nmax/256, 2, B);
+// side 0: rows (NCHUNK column-chunk partials each), side 1: columns (nrb row-block partials each)
+__global__ __launch_bounds__(256) void lse_final_kernel(const float* __restrict__ partr, const float* __restrict__ partc,
+                                                        float* __restrict__ lse2, int use_dustbin, float beta2, int n0, int n1,
+                                                        int nmax, int nrb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, side = blockIdx.y, b = blockIdx.z;
+  if (idx >= (side ? n1 : n0)) return;
   float m = -1e30f, s = 0.f;
+  if (side == 0) {
 #pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) {
-    const float* q = part + ((bs * NCHUNK + c) * nmax + row) * 2;
-    lse2_merge(m, s, q[0], q[1]);
-  }
-  if (use_dustbin) lse2_merge(m, s, beta2, 1.0f);
-  lse2[bs * nmax + row] = m + __builtin_amdgcn_logf(s);   // v_log_f32 is log2
-}
-
-// pass 2.  grid (row blocks of 128, NCHUNK2, B), one wave per 32 rows: recompute the tile, write
-// scores = softmax_rows * softmax_cols = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores * kp
-template <bool FULLC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_write_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
-                                                                 const float* __restrict__ scr0, const float* __restrict__ scr1,
-                                                                 float scale2, const float* __restrict__ lse2,
-                                                                 float* __restrict__ scores, float* __restrict__ kp,
-                                                                 float* __restrict__ fin, int C, int n0, int n1, int nmax,
-                                                                 int gx, int nunits) {
-  int bx, by, b;
-  if (!decode_unit_grid(gx, NCHUNK2, nunits, bx, by, b)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int i0 = (bx * 4 + wave) * RT;
-  if (i0 >= n0) return;
-  float a[CMAX / 2], bq[CMAX / 2];
-  load_operand<FULLC>(a, dsc0 + (long long)b * C * n0, C, n0, i0 + l31, hi);
-  float lr[16], s0[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    lr[r] = i < n0 ? lse2[((long long)b * 2 + 0) * nmax + i] : 0.f;
-    s0[r] = (scr0 && i < n0) ? scr0[(long long)b * n0 + i] : 0.f;
-  }
-  const float* dB = dsc1 + (long long)b * C * n1;
-  const int ntB = (n1 + RT - 1) / RT;
-  const int per = (ntB + NCHUNK2 - 1) / NCHUNK2;
-  const int jt0 = by * per, jt1 = min(ntB, jt0 + per);
-  for (int jt = jt0; jt < jt1; ++jt) {
-    const int j = jt * RT + l31;
-    load_operand<FULLC>(bq, dB, C, n1, j, hi);
-    const f32x16 acc = corr_regs<FULLC>(a, bq, C);
-    MK_LOADS_THEN_MFMAS();
-    if (j >= n1) continue;
-    const float lc = lse2[((long long)b * 2 + 1) * nmax + j];
-    const float s1 = scr1 ? scr1[(long long)b * n1 + j] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (i >= n0) continue;
-      const float v = acc[r] * scale2;
-      const float pr = __builtin_amdgcn_exp2f((v - lc) + (v - lr[r]));  // softmax over dim 1 times softmax over dim 2
-      const long long o = ((long long)b * n0 + i) * n1 + j;
-      const float kk = s0[r] * s1;
-      if (scores) scores[o] = pr;
-      if (kp) kp[o] = kk;
-      if (fin) fin[o] = pr * kk;
+    for (int c = 0; c < NCHUNK; ++c) {
+      const float* q = partr + (((long long)b * NCHUNK + c) * n0 + idx) * 2;
+      lse2_merge(m, s, q[0], q[1]);
+    }
+  } else {
+    for (int rb = 0; rb < nrb; ++rb) {
+      const float* q = partc + (((long long)b * nrb + rb) * n1 + idx) * 2;
+      lse2_merge(m, s, q[0], q[1]);
     }
   }
+  if (use_dustbin) lse2_merge(m, s, beta2, 1.0f);
+  lse2[((long long)b * 2 + side) * nmax + idx] = m + __builtin_amdgcn_logf(s);   // v_log_f32 is log2
+}
+
+// pass 2, element-wise.  grid (column blocks of 256*VEC, n0, B): scores = softmax_rows * softmax_cols =
+// 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores * kp.  `scores` or `fin` may alias vbuf (in place).
+template <int VEC>
+__global__ __launch_bounds__(256) void dual_softmax_apply_kernel(const float* vbuf, const float* __restrict__ scr0,
+                                                                 const float* __restrict__ scr1, const float* __restrict__ lse2,
+                                                                 float* scores, float* __restrict__ kp, float* fin, int n0, int n1,
+                                                                 int nmax) {
+  const int i = blockIdx.y, b = blockIdx.z;
+  const int j = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (j >= n1) return;
+  const float lr = lse2[((long long)b * 2 + 0) * nmax + i];
+  const float s0 = scr0 ? scr0[(long long)b * n0 + i] : 0.f;
+  const long long o = ((long long)b * n0 + i) * n1 + j;
+  typedef float VT __attribute__((ext_vector_type(VEC)));
+  const VT v = *(const VT*)(vbuf + o);
+  const VT lc = *(const VT*)(lse2 + ((long long)b * 2 + 1) * nmax + j);
+  VT s1, pr, kk, ff;
+  if (scr1) s1 = *(const VT*)(scr1 + (long long)b * n1 + j);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float p = __builtin_amdgcn_exp2f((v[e] - lc[e]) + (v[e] - lr));
+    const float k = scr1 ? s0 * s1[e] : 0.f;
+    pr[e] = p;
+    kk[e] = k;
+    ff[e] = p * k;
+  }
+  if (scores) *(VT*)(scores + o) = pr;
+  if (kp) *(VT*)(kp + o) = kk;
+  if (fin) *(VT*)(fin + o) = ff;
 }
 
 // ---- sinkhorn ---------------------------------------------------------------------------------------
@@ -462,8 +479,9 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 extern "C" {
 
 long long mk_dual_softmax_work_floats(int B, int n0, int n1) {
-  const int nmax = n0 > n1 ? n0 : n1;
-  return (long long)B * 2 * NCHUNK * nmax * 2 + (long long)B * 2 * nmax;   // chunk partials + final log2-sum-exp vectors
+  const long long nmax = n0 > n1 ? n0 : n1, nrb = (n0 + RT - 1) / RT;
+  // row partials + column partials + final log2-sum-exp vectors + the stored correlation (unused when `scores` is given)
+  return (long long)B * NCHUNK * n0 * 2 + (long long)B * nrb * n1 * 2 + (long long)B * 2 * nmax + 4 + (long long)B * n0 * n1;
 }
 
 int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
@@ -473,28 +491,37 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
   MK_CHECK_ARG(B > 0 && n0 > 0 && n1 > 0 && C > 0 && C <= CMAX && C % 2 == 0, "mk_dual_softmax: need 0 < C <= %d, C even", CMAX);
   MK_CHECK_ARG((scr0 && scr1) || (!kp_scores && !final_scores), "mk_dual_softmax: kp/final scores need scr0 and scr1");
   hipStream_t st = (hipStream_t)stream;
-  const int nmax = n0 > n1 ? n0 : n1;
+  const int nmax = n0 > n1 ? n0 : n1, nrb = (n0 + RT - 1) / RT;
   const float LOG2E = 1.4426950408889634f;
   const float scale2 = inv_temperature * LOG2E;
-  float* part = work;
-  float* lse2 = work + (long long)B * 2 * NCHUNK * nmax * 2;
-  const int gx1 = (nmax + 4 * RT - 1) / (4 * RT), gx2 = (n0 + 4 * RT - 1) / (4 * RT);
-  const dim3 g1((unsigned)gx1 * NCHUNK * ((B * 2 + 7) / 8 * 8)), g2((unsigned)gx2 * NCHUNK2 * ((B + 7) / 8 * 8));   // see decode_unit_grid
+  float* partr = work;
+  float* partc = partr + (long long)B * NCHUNK * n0 * 2;
+  float* lse2 = partc + (long long)B * nrb * n1 * 2;
+  float* vown = lse2 + (((long long)B * 2 * nmax + 3) & ~3LL);   // 16-byte aligned when `work` is
+  // in place when the caller wants `scores` or `final_scores` anyway (pass 2 reads an element, then overwrites it)
+  float* vbuf = scores ? scores : final_scores ? final_scores : vown;
+  const int gx1 = (n0 + 4 * RT - 1) / (4 * RT);
+  const dim3 g1((unsigned)gx1 * NCHUNK * ((B + 7) / 8 * 8));   // see decode_unit_grid
   if (C == CMAX)
-    hipLaunchKernelGGL(lse_partial_kernel<true>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, part, C, n0, n1, nmax, gx1, B * 2);
+    hipLaunchKernelGGL(lse_partial_kernel<true>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, partr, partc, vbuf, C, n0, n1, nrb, gx1, B);
   else
-    hipLaunchKernelGGL(lse_partial_kernel<false>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, part, C, n0, n1, nmax, gx1, B * 2);
+    hipLaunchKernelGGL(lse_partial_kernel<false>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, partr, partc, vbuf, C, n0, n1, nrb, gx1, B);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lse_final_kernel, dim3((nmax + 255) / 256, 2, B), dim3(256), 0, st, part, lse2, use_dustbin, dustbin * LOG2E, n0,
-                     n1, nmax);
+  hipLaunchKernelGGL(lse_final_kernel, dim3((nmax + 255) / 256, 2, B), dim3(256), 0, st, partr, partc, lse2, use_dustbin,
+                     dustbin * LOG2E, n0, n1, nmax, nrb);
   MK_CHECK_LAUNCH();
-  if (C == CMAX)
-    hipLaunchKernelGGL(dual_softmax_write_kernel<true>, g2, dim3(256), 0, st, dsc0, dsc1, scr0, scr1, scale2, lse2, scores,
-                       kp_scores, final_scores, C, n0, n1, nmax, gx2, B);
-  else
-    hipLaunchKernelGGL(dual_softmax_write_kernel<false>, g2, dim3(256), 0, st, dsc0, dsc1, scr0, scr1, scale2, lse2, scores,
-                       kp_scores, final_scores, C, n0, n1, nmax, gx2, B);
-  MK_CHECK_LAUNCH();
+  if (scores || kp_scores || final_scores) {
+    // rows of vbuf / outputs start at multiples of n1 floats: 8-byte vectors need n1 even and 8-byte-aligned bases
+    const bool v2 = (n1 % 2 == 0) && ((((uintptr_t)vbuf | (uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores |
+                                        (uintptr_t)scr1 | (uintptr_t)lse2) & 7) == 0) && (nmax % 2 == 0);
+    if (v2)
+      hipLaunchKernelGGL(dual_softmax_apply_kernel<2>, dim3((n1 / 2 + 255) / 256, n0, B), dim3(256), 0, st, vbuf, scr0, scr1, lse2,
+                         scores, kp_scores, final_scores, n0, n1, nmax);
+    else
+      hipLaunchKernelGGL(dual_softmax_apply_kernel<1>, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, vbuf, scr0, scr1, lse2, scores,
+                         kp_scores, final_scores, n0, n1, nmax);
+    MK_CHECK_LAUNCH();
+  }
   return MK_OK;
 }
 
