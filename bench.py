@@ -227,6 +227,7 @@ def parse_args(argv=None):
                     help="also report the PCIe-inclusive rate under 'pcie_inclusive' (default at N=1): uint8 frames from host "
                          "memory through the input pipeline (pinned ring, H2D, resize kernel) into the forward; never `value`")
     ap.add_argument("--no-h2d", dest="include_h2d", action="store_false", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-pair latency leg reported under 'single_pair'")
     ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
     ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -461,9 +462,20 @@ def main(argv=None):
         out["alt"] = {"dtype": "fp16", "value": B * a2.steps / dt16, "unit": "pairs/s", "steps": a2.steps,
                       "note": "fp16 operands are the reference's own low-precision mode (MICKEY.DINOV2.FLOAT16)"}
         del m16
-    if rank == 0 and args.include_h2d and not use_dist:
-        from mickey_amd import input_pipeline as ip
-        out["pcie_inclusive"] = ip.bench_h2d(make_model(args.dtype)[0], B, H, W, steps=max(2, min(args.steps, 3)))
+    if rank == 0 and not use_dist and (args.include_h2d or not args.no_single):
+        m2 = make_model(args.dtype)[0]
+        if args.include_h2d:
+            from mickey_amd import input_pipeline as ip
+            out["pcie_inclusive"] = ip.bench_h2d(m2, B, H, W, steps=max(2, min(args.steps, 3)))
+        if not args.no_single and B != 1:
+            # BASELINE.json configs[1]: ONE 540x720 pair (latency; the forward is replayed as a hipGraph when AMD.GRAPH allows)
+            d1 = {k: v.to(dev) for k, v in syn.synthetic_batch(B=1, H=H, W=W, seed=99).items()}
+            a1 = argparse.Namespace(**vars(args))
+            a1.steps, a1.warmup = 20, 5
+            dt1, _, _ = measure(m2, d1, a1, False, 1, None, None)
+            out["single_pair"] = {"value": a1.steps / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / a1.steps * 1e3, "steps": a1.steps,
+                                  "hip_graph": len(m2._graphs) > 0, "what": "BASELINE.json configs[1]: batch of one pair, same model"}
+        del m2
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-alt --no-h2d > /tmp/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-alt --no-h2d --no-single > /tmp/pmc_$c.log 2>&1
 done
 python - <<'PY'
 import csv, glob, json, collections
