@@ -58,7 +58,7 @@ class StageProfiler:
     # stage -> (governing bound, unit of work)
     STAGES = {
         "encoder_gemm": ("mfma", "flop"), "attention": ("mfma", "flop"), "conv_gemm": ("mfma", "flop"),
-        "head_gemm": ("mfma", "flop"), "layernorm": ("hbm", "byte"), "matcher": ("hbm", "byte"), "sampler": ("hbm", "byte"),
+        "head_gemm": ("hbm", "byte"), "layernorm": ("hbm", "byte"), "matcher": ("hbm", "byte"), "sampler": ("hbm", "byte"),
         "hypotheses_refine": (None, None),
     }
 
@@ -96,7 +96,9 @@ class StageProfiler:
         timed("conv3x3", "conv_gemm",
               lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, zp, act=0, in2=None, C2=0, **k:
               2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
-        timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k: 2.0 * groups * M * N * K)
+        # the head linears (K = 128..256, fp32 qkv outputs) are write-bound: 1 flop per 3 bytes; priced against HBM
+        timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:
+              float(groups) * (M * K * esz(a) + N * K * esz(w) + M * N * esz(out)))
 
         def ln_bytes(x, w, b, eps, out=None, out_dtype=None, resid=None, rows_out=None, **k):
             D = w.shape[-1]

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restric
   const float* base = qkv + gi * (long long)L * 3 * C;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ks = 0.f;
+#pragma unroll 8   // 8 rows of loads in flight per thread (the sums stay in token order): the loop is latency-bound otherwise
   for (int s = s0; s < s1; ++s) {
     const float* row = base + (long long)s * 3 * C;
     const float kd = phi(row[C + h * 16 + d]);
