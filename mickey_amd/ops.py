@@ -1,11 +1,10 @@
 """Tensor-level wrappers over the C ABI (include/mickey_hip.h).  Each function allocates its outputs
 with torch (device memory only), passes raw pointers + the current HIP stream to libmickey_hip.so and
 returns tensors.  No arithmetic happens here."""
-import math
 
 import torch
 
-from . import _native as nv
+
 from ._native import ACT_GELU, ACT_NONE, ACT_RELU, call, dtype_code, ptr, query, stream  # noqa: F401
 
 LOG2E = 1.4426950408889634

@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from .synthetic import DINO_PREFIX, DUSTBIN_KEY, EXTRACTOR_PREFIX, HEADS, VIT_ARCH
+from .synthetic import DINO_PREFIX, DUSTBIN_KEY, EXTRACTOR_PREFIX, HEADS
 
 PATCH_K = 640  # 588 padded to a multiple of the 64-wide K tile
 

@@ -45,7 +45,8 @@ def test_abi_rejects_bad_arguments_without_a_device(nv):
     assert lib.mk_gemm(None, 0, None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
     assert b"gemm" in lib.mk_last_error()
     assert lib.mk_layernorm(None, 0, None, None, 1e-6, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
-    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12) == 2 * 2 * 4 * 12 * 2 + 2 * 2 * 12   # chunk partials + final LSE vectors
+    # row partials (4 column chunks) + column partials (1 row block) + final LSE vectors + pad + the stored correlation
+    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4 + 2 * 10 * 12
     assert nv.query("mk_exprace_topk_work_bytes", 1, 20, 2048) > 20 * 8192 * 8
     with pytest.raises(nv.MickeyHipError):
         nv.call("mk_flash_attn_fwd", None, None, None, None, 0, 0, 0, 0, 0, 0, None)

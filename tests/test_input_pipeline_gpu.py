@@ -1,6 +1,5 @@
 """-m gpu: the input pipeline kernel / feeder against the oracle's restatement of the reference's
 read_color_image / correct_intrinsic_scale (lib/datasets/utils.py:61-99)."""
-import io
 
 import numpy as np
 import pytest

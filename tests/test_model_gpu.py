@@ -5,7 +5,6 @@ Tolerances: the HIP path computes the encoder and head contractions with 16-bit 
 accumulation (the reference ships an fp16 encoder + fp32 heads); its distance to the fp32 oracle is a
 precision noise floor, not an algorithmic difference.  The floor of the REFERENCE's own fp16 mode on the
 golden case is stored in tests/golden/noise_floor_fp16.npz; bounds below are stated per quantity."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """Row N3 on the GPU: mk_train_ransac_masks / mk_reinforce_scatter and the MetricPoseLoss drop-in against the oracle and
 against the reference's own outputs (tests/golden/train_ransac.npz: the reference's torch.multinomial draws are replayed)."""
-import numpy as np
 import pytest
 import torch
 
