@@ -122,6 +122,32 @@ def test_sampler_philox_properties():
     assert first > second
 
 
+def test_sampler_prefilter_many_rows_and_frequencies():
+    """The Philox collect pass draws the uniforms in two parts (6-bit pre-filter + 18 low bits for the survivors; rows in
+    groups of 20 per stage-1 call).  40 rows exercise two groups; inclusion frequencies of a skewed 4096-cell problem over
+    40 rows x 30 calls must match torch.multinomial's (two-sample chi-square), and every row is a valid draw."""
+    from mickey_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    ncell, k, rows = 4096, 256, 40
+    p = (torch.rand(1, ncell, generator=g) ** 6 + 1e-4)
+    p[0, :50] += 3.0                       # a few dominant cells (they take the "large p" path: every row queued)
+    f_hip = torch.zeros(ncell, dtype=torch.float64)
+    for call in range(30):
+        idx, cnt = ops.exprace_topk(p.to(dev), rows, k, seed=3, offset=call)
+        idx = idx.cpu().long()
+        assert (cnt.cpu() == k).all()
+        srt = torch.sort(idx, -1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+        assert not torch.equal(idx[3], idx[23])    # rows of different stage-1 groups are different draws
+        f_hip += torch.bincount(idx.reshape(-1), minlength=ncell).double()
+    f_ref = torch.bincount(torch.multinomial(p.expand(rows * 30, ncell), k, generator=g).reshape(-1), minlength=ncell).double()
+    keep = (f_hip + f_ref) >= 10
+    chi2 = float((((f_hip - f_ref) ** 2) / (f_hip + f_ref))[keep].sum())
+    dof = int(keep.sum())
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5, (chi2, dof)
+
+
 def test_sampler_degenerate_inputs():
     from mickey_amd import ops
     dev = _dev()
