@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < D) dst[i] = *(const f32x4*)(xr + c);
+      if (c < D) dst[i] = __builtin_nontemporal_load((const f32x4*)(xr + c));   // streamed once: do not displace the weights in L2
     }
   };
   load_row(r0, v[0]);
