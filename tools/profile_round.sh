@@ -10,7 +10,7 @@ timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-alt --no-h2d --no-s
 cd /tmp
 rm -rf /tmp/prof_r02
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r02 -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt --no-h2d --no-single > /tmp/prof_r02.log 2>&1
-tail -1 /tmp/prof_r02.log > $R/gpurun_out/r02_bench_b32_under_rocprof.json
+grep "^{\"metric\"" /tmp/prof_r02.log | tail -1 > $R/gpurun_out/r02_bench_b32_under_rocprof.json
 cp $(ls /tmp/prof_r02/*kernel_stats.csv | head -1) $R/gpurun_out/r02_bench_b32_kernel_stats.csv
 bash $R/tools/pmc_bench_traffic.sh > /tmp/pmc_traffic.log 2>&1; tail -2 /tmp/pmc_traffic.log
 head -c 600 $R/gpurun_out/r02_bench_b32.json; echo; head -5 $R/gpurun_out/r02_bench_b32_kernel_stats.csv | cut -c1-220
