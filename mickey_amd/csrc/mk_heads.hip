@@ -49,12 +49,11 @@ __global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restric
   const float* base = qkv + gi * (long long)L * 3 * C;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ks = 0.f;
-#pragma unroll 8   // 8 rows of loads in flight per thread (the sums stay in token order): the loop is latency-bound otherwise
   for (int s = s0; s < s1; ++s) {
     const float* row = base + (long long)s * 3 * C;
-    const float kd = phi(row[C + h * 16 + d]);
-    const f32x4 v0 = *(const f32x4*)(row + 2 * C + h * 16 + vh * 8);
-    const f32x4 v1 = *(const f32x4*)(row + 2 * C + h * 16 + vh * 8 + 4);
+    const float kd = phi(__builtin_nontemporal_load(row + C + h * 16 + d));
+    const f32x4 v0 = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + h * 16 + vh * 8));
+    const f32x4 v1 = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + h * 16 + vh * 8 + 4));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[e] += kd * (v0[e] * invL);

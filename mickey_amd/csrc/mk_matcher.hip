@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void dual_softmax_apply_kernel(const float* vb
   const float s0 = scr0 ? scr0[(long long)b * n0 + i] : 0.f;
   const long long o = ((long long)b * n0 + i) * n1 + j;
   typedef float VT __attribute__((ext_vector_type(VEC)));
-  const VT v = *(const VT*)(vbuf + o);
+  const VT v = __builtin_nontemporal_load((const VT*)(vbuf + o));   // read once, overwritten in place
   const VT lc = *(const VT*)(lse2 + ((long long)b * 2 + 1) * nmax + j);
   VT s1, pr, kk, ff;
   if (scr1) s1 = *(const VT*)(scr1 + (long long)b * n1 + j);
