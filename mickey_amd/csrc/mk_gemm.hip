@@ -116,7 +116,10 @@ template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   // 256x256 tiles need enough of them to fill 256 CUs (1 workgroup per CU); otherwise 128x128 (2 per CU)
   const long long big_tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * groups;
-  bool big = p.N >= 256 && big_tiles >= 224;  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md)
+  // measured: +12..18 % over 128x128 at M >= 31k (profiles/r01_gemm_pmc.md); at 192 tiles (one pair, qkv: 16 x 12) the
+  // ping-pong kernel on 75 % of the CUs still beats 744 tiles of 128x128 (30.6 vs 35.6 us); at 64 tiles (proj / fc2 of one
+  // pair) it loses 2x
+  bool big = p.N >= 256 && big_tiles >= 192;
   // the 256x256 kernels address operands with 32-bit element offsets and run a software pipeline of >= 2 K stages
   // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
