@@ -1,6 +1,8 @@
 #!/bin/bash
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd /tmp; rm -rf /tmp/prof_s
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-h2d --no-single > /tmp/prof_s.log 2>&1
-cp $(ls /tmp/prof_s/*kernel_stats.csv | head -1) $R/gpurun_out/r2_small_stats.csv
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -q -x -m gpu 2>&1 | tail -4 > gpurun_out/r02_pytest_gpu.txt
+cat gpurun_out/r02_pytest_gpu.txt
+timeout 300 python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-alt --no-h2d --no-single 2>/dev/null | tail -1 > gpurun_out/r02_bench_b1.json
+python -c "
+import json
+d=json.load(open('gpurun_out/r02_bench_b1.json')); print(d['value'], d['ms_per_step']); [print(s['stage'], round(s['ms_per_step'],3)) for s in d['roofline']['stages']]"
