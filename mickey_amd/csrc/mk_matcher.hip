@@ -6,11 +6,11 @@
 // The N x M x C correlation runs on the EXACT-fp32 matrix core path (v_mfma_f32_32x32x2_f32, bitwise
 // an fp32 fma chain), because `final_scores` feeds a sampler and must match the fp32 reference to
 // round-off.  The (n0+1) x (n1+1) coupling matrix is never materialised:
-//   pass 1  row log-sum-exp of S and of S^T (= column LSE) as online (max, sum) partials per column
-//           chunk; descriptor tiles staged in LDS; 64x64 tile per workgroup, 32x32 per wave;
-//   pass 2  recompute the tile, merge the partials (+ dustbin term), write
-//           scores, kp_scores = scr0 (x) scr1, final_scores = scores * kp_scores   (each optional)
-// Pass 2 is HBM-write-bound (3 x n0 x n1 x 4 B); stores are 128 B contiguous per 32 lanes.
+//   pass 1  ONE correlation: online (max, sum) partials of the rows of S (per column chunk) and of its columns (per
+//           32-row block) from the same register-resident tile; the scaled correlation is stored;
+//   merge   partials (+ dustbin term) -> log2-sum-exp vectors of both directions;
+//   pass 2  element-wise: scores = 2^((v - lse_col) + (v - lse_row)), kp_scores = scr0 (x) scr1,
+//           final_scores = scores * kp_scores (each optional), in place over the stored correlation where possible.
 #include "mk_common.hpp"
 
 namespace {
