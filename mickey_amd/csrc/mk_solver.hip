@@ -4,10 +4,13 @@
 // The reference materialises a [20B, n*n] tiled copy of final_scores (300 MB / pair), a same-sized
 // Exp(1) noise tensor and a full top-k for its outer torch.multinomial, then tiles X/Y 100x for the
 // inner one.  Here:
-//   * mk_exprace_topk: a threshold from the histogram of p alone (expected tail count of the race keys), ONE
-//     streamed read of final_scores per group of 4 rows with Philox noise generated in registers, small in-LDS
-//     bitonic sort -> the same "top-k of p / Exp(1)" selection, in the same (descending key) order torch.topk
-//     returns; an exact radix-histogram path takes over on device if a row collected too few / too many.
+//   * mk_exprace_topk: a threshold from the histogram of p alone (expected tail count of the race keys), ONE collect
+//     pass with Philox noise generated in registers (uniforms drawn in two parts: a 6-bit pre-filter for all rows of a
+//     cell from one call, the low bits only for the 1-in-64 survivors; injected noise: one streamed read per group of 4
+//     rows), small in-LDS bitonic sort -> the same "top-k of p / Exp(1)" selection, in the same (descending key) order
+//     torch.topk returns; an exact radix-histogram path takes over on device if a row collected too few / too many.
+//   * mk_train_ransac_masks / mk_reinforce_scatter: the training-time RANSAC of loss/loss_class.py (8-point hypotheses,
+//     refinement of every hypothesis, REINFORCE bookkeeping).
 //   * mk_ransac_hypotheses: a correspondence set (X, Y, w: 56 KB) is staged once in LDS and shared by
 //     all its hypotheses; one wave per hypothesis: exponential-race 3-sample (wave arg-max), 3x3
 //     Kabsch via one-sided Jacobi SVD in fp64 (warp-serial, no MFMA), soft inlier count by wave64
