@@ -90,6 +90,8 @@ class StageProfiler:
         timed("gemm_ls_residual", "encoder_gemm", mnk)
         timed("gemm_qkv", "encoder_gemm", mnk)
         timed("gemm_patch_embed", "encoder_gemm", mnk)
+        for nm in ("gemm_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_patch_embed_ln"):   # LayerNorm folded in
+            timed(nm, "encoder_gemm", mnk)
         # attention.py:53-59: per (image, head) QK^T and PV, 2 * 2 * N^2 * 64
         timed("flash_attn", "attention", lambda q, k, vt, out, nimg, heads, ntok, pad: 4.0 * nimg * heads * ntok * ntok * 64)
         # implicit-GEMM 3x3 conv: 2 * M * Cout * (9 C1 + C2) per group
@@ -230,6 +232,7 @@ def parse_args(argv=None):
                          "memory through the input pipeline (pinned ring, H2D, resize kernel) into the forward; never `value`")
     ap.add_argument("--no-h2d", dest="include_h2d", action="store_false", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-pair latency leg reported under 'single_pair'")
+    ap.add_argument("--no-ln-fold", action="store_true", help="dev: stand-alone LayerNorm kernels instead of the folded form (A/B)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
     ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -392,6 +395,7 @@ def main(argv=None):
         cfg = default_cfg()
         cfg["AMD"]["ENCODER_DTYPE"] = dtype
         cfg["AMD"]["SEED"] = rank
+        cfg["AMD"]["LN_FOLD"] = not args.no_ln_fold
         cfg["AMD"]["GRAPH"] = {"auto": "auto", "on": True, "off": False}[args.graph]
         sd = syn.mickey_state_dict(cfg, seed=0)
         m = MickeyRelativePose(cfg)

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   Stager<T, AMODE, NW, AJ, WJ> st;
   st.init(p, g, m0, n0, wave, lane);
   st.issue(p, smem, smem + A_BYTES, 0);
+  // folded LayerNorm (consumer): row parameters of the tile into LDS while the first stage is in flight
+  float2* lnp = (float2*)(smem + 2 * STAGE_BYTES);
+  if (AMODE == A_DENSE && p.ln_stats) ln_params_to_lds<BM, NW * 64>(p, m0, tid, lnp);
   f32x4 acc[WMF][4];
 #pragma unroll
   for (int i = 0; i < WMF; ++i)
@@ -87,12 +90,12 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
     }
   }
-  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g);
+  epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g, lnp);
 }
 
 template <typename T, int AMODE>
 int launch_small(const GemmParams& p, int groups, hipStream_t st) {
-  constexpr int LDS = 2 * 256 * 128;
+  constexpr int LDS = 2 * 256 * 128 + 128 * 8;   // two stages + the folded LayerNorm's row parameters
   static bool attr_done = false;  // benign race: the attribute call is idempotent
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -124,10 +127,15 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
                     (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
-  if (dtype == MK_F32) return launch_f32(p, groups, AMODE, st);   // exact parity mode: one plain schedule
+  const bool ln_fold = p.ln_stats || p.xlp_out;
+  if (dtype == MK_F32) {   // exact parity mode: one plain schedule, LayerNorm as its own kernel
+    MK_CHECK_ARG(!ln_fold, "gemm: the folded-LayerNorm epilogues exist for 16-bit operands only");
+    return launch_f32(p, groups, AMODE, st);
+  }
   int sched = g_schedule;
   if (sched == 0) sched = (big && k_ok) ? MK_GEMM_DEFAULT_BIG : 1;
   if (!k_ok) sched = 1;
+  if (sched == 10 && ln_fold) sched = 7;   // the one-wave-per-SIMD A/B partner has no folded-LayerNorm epilogue
   if (sched == 10) return launch_w4(p, groups, dtype, AMODE, st, g_band_m);
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
   return dtype == MK_BF16 ? launch_small<__bf16, AMODE>(p, groups, st) : launch_small<_Float16, AMODE>(p, groups, st);
@@ -228,6 +236,66 @@ int mk_gemm_patch_embed(const void* A, int lda, const void* W, int ldw, const fl
   p.epi = MK_EPI_PATCH; p.bias = bias; p.pos = pos; p.npatch = npatch; p.out_f32 = x; p.ldc = D;
   if (int e = check_common(p, dtype)) return e;
   MK_CHECK_ARG(bias && pos && x && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed: bad args");
+  return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
+}
+
+
+// ---- LayerNorm folded into the GEMMs around it (reference block.py:84-88,105-106: x + ls(f(norm(x)))) ----
+// producer: the residual / patch-embed epilogue also emits the new rows in 16 bit (raw) and their partial statistics;
+// consumer: A = those raw rows, W = W.diag(ln_weight), and the epilogue applies rstd / mean per row.
+static int ln_consumer_args(GemmParams& p, const float* colsum, const float* stats, float eps, const char* who) {
+  MK_CHECK_ARG(colsum && stats && p.bias, "%s: colsum, stats and bias are required", who);
+  MK_CHECK_ARG(p.lda == p.K, "%s: the normalised width is K: lda must equal K", who);
+  p.ln_colsum = colsum; p.ln_stats = stats; p.ln_nslot = p.K / 64; p.ln_eps = eps;
+  return MK_OK;
+}
+
+int mk_gemm_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
+               float eps, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream) {
+  GemmParams p = {};
+  p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+  p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = ldc; p.out_lp = out;
+  if (int e = check_common(p, dtype)) return e;
+  MK_CHECK_ARG(lda % 8 == 0 && ldc % 4 == 0 && ldc >= N && out && (act == MK_ACT_NONE || act == MK_ACT_GELU), "mk_gemm_ln: bad args");
+  if (int e = ln_consumer_args(p, colsum, stats, eps, "mk_gemm_ln")) return e;
+  return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
+}
+
+int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
+                   float eps, void* q, void* k, void* vt, int nimg, int ntok, int ntok_pad, int heads, float qscale, int dtype,
+                   mk_stream_t stream) {
+  GemmParams p = {};
+  const int D = heads * 64;
+  p.A = A; p.W = W; p.M = nimg * ntok; p.N = 3 * D; p.K = D; p.lda = lda; p.ldw = ldw;
+  p.epi = MK_EPI_QKV; p.bias = bias; p.q = q; p.k = k; p.vt = vt;
+  p.ntok = ntok; p.ntok_pad = ntok_pad; p.heads = heads; p.qscale = qscale;
+  if (int e = check_common(p, dtype)) return e;
+  MK_CHECK_ARG(q && k && vt && ntok_pad % 64 == 0 && ntok_pad >= ntok && lda % 8 == 0, "mk_gemm_qkv_ln: bad args");
+  if (int e = ln_consumer_args(p, colsum, stats, eps, "mk_gemm_qkv_ln")) return e;
+  return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
+}
+
+int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, float* x,
+                           int ldx, void* xlp, int ldxlp, float* stats, int M, int N, int K, int dtype, mk_stream_t stream) {
+  GemmParams p = {};
+  p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
+  p.epi = MK_EPI_LS_RESIDUAL; p.bias = bias; p.gamma = gamma; p.out_f32 = x; p.ldc = ldx;
+  p.xlp_out = xlp; p.ldxlp = ldxlp; p.stats_out = stats; p.nslot_out = N / 64;
+  if (int e = check_common(p, dtype)) return e;
+  MK_CHECK_ARG(bias && gamma && x && lda % 8 == 0 && lda >= K && ldx % 4 == 0 && ldx >= N, "mk_gemm_ls_residual_ln: bad args");
+  MK_CHECK_ARG(xlp && stats && N % 64 == 0 && ldxlp % 8 == 0 && ldxlp >= N, "mk_gemm_ls_residual_ln: xlp / stats / N %% 64");
+  return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
+}
+
+int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, float* x,
+                           void* xlp, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream) {
+  GemmParams p = {};
+  p.A = A; p.W = W; p.M = nimg * npatch; p.N = D; p.K = K; p.lda = lda; p.ldw = ldw;
+  p.epi = MK_EPI_PATCH; p.bias = bias; p.pos = pos; p.npatch = npatch; p.out_f32 = x; p.ldc = D;
+  p.xlp_out = xlp; p.ldxlp = D; p.stats_out = stats; p.nslot_out = D / 64;
+  if (int e = check_common(p, dtype)) return e;
+  MK_CHECK_ARG(bias && pos && x && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed_ln: bad args");
+  MK_CHECK_ARG(xlp && stats && D % 64 == 0, "mk_gemm_patch_embed_ln: xlp / stats / D %% 64");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 

@@ -43,7 +43,111 @@ struct GemmParams {
   // patch embed
   const float* pos;
   int npatch;
+  // ---- LayerNorm folded into the GEMMs around it (the encoder's pre-norm blocks) ----
+  // producer side (LS_RESIDUAL / PATCH epilogues): besides the fp32 rows, a 16-bit copy of the NEW rows (the raw, un-
+  // normalised A operand of the next GEMM) and their partial statistics: (sum, sum of squares) per 64-column slot
+  void* xlp_out;          // [rows, ldxlp] 16 bit, indexed like out_f32
+  int ldxlp;
+  float* stats_out;       // [rows][nslot_out][2]
+  int nslot_out;          // N / 64
+  // consumer side (QKV / STORE epilogues, 16-bit outputs): A = raw rows, W = W.diag(ln_weight) (folded on the host),
+  //   out[m][n] = rstd_m * acc[m][n] - rstd_m * mean_m * colsum[n] + bias[n],   bias = b + W.ln_bias (folded on the host)
+  const float* ln_stats;  // [M][ln_nslot][2] as written by the producer; null = plain GEMM
+  const float* ln_colsum; // [N]: sum_k W'[n][k] of the 16-bit-rounded folded weights
+  int ln_nslot;           // K / 64
+  float ln_eps;
 };
+
+// 16-lane (one DPP row) all-reduce: every lane of the row ends up with the same sum
+__device__ __forceinline__ float row16_sum(float v) {
+#define MK_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  MK_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  MK_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  MK_DPP_ADD(0x141);   // row_half_mirror
+  MK_DPP_ADD(0x140);   // row_mirror
+#undef MK_DPP_ADD
+  return v;
+}
+
+// Consumer prologue of the folded LayerNorm: (rstd, -mean * rstd) of the tile's BM rows into LDS (prm[BM]), from the
+// producer's per-slot partial sums.  NT = 2 * BM threads: thread t sums one half of the slots of row t >> 1 (fixed
+// order: the result does not depend on the schedule), the pair is combined in fp64 (E[x^2] - mean^2 without the fp32
+// cancellation).  The K loop's barriers order the LDS writes before the epilogue that reads them.
+// In the 256x256 kernel the D = 1024 case is split in two so that the loads are issued BEFORE the first LDS-DMA stage and
+// consumed while it is in flight: LnRowLoads16::issue() (inline-asm loads, invisible to hipcc's vmcnt bookkeeping like the
+// DMA pieces themselves) ... DMA pieces ... finish<n_younger>() waits with a counted vmcnt for exactly these loads.
+// Every other width takes the plain path below (ln_params_to_lds).
+// 16 slots per row (D = 1024, ViT-L): the tile's statistics are one contiguous block of 256 rows x 128 B.  Each wave reads
+// 4 KiB of it with 4 fully coalesced 16-byte loads per lane (a per-row gather -- 64 lanes x 8 B on 32 different lines per
+// instruction -- cost ~1.5 us of address coalescing per tile in front of the first barrier); lane l of load j then holds
+// slots 2c, 2c + 1 (c = l & 7) of row 32 * wave + 8 * j + (l >> 3): an 8-lane DPP reduction finishes the row.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+struct LnRowLoads16 {
+  u32x4 v[4];
+  __device__ __forceinline__ void issue(const GemmParams& p, int m0, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const long long last = (long long)p.M * 128 - 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long off = ((long long)(m0 + wave * 32 + j * 8) * 128) + lane * 16;
+      off = off < last ? off : last;   // rows past M: any valid address (their parameters are never used)
+      const char* a = (const char*)p.ln_stats + off;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(a) : "memory");
+    }
+  }
+  // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight
+  template <int YOUNGER>
+  __device__ __forceinline__ void finish(const GemmParams& p, int tid, float2* prm) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 f = __builtin_bit_cast(f32x4, v[j]);
+      float s = f[0] + f[2], q = f[1] + f[3];
+#define MK_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+      MK_DPP_ADD(s, 0xB1);  MK_DPP_ADD(q, 0xB1);     // quad_perm [1,0,3,2]
+      MK_DPP_ADD(s, 0x4E);  MK_DPP_ADD(q, 0x4E);     // quad_perm [2,3,0,1]
+      MK_DPP_ADD(s, 0x141); MK_DPP_ADD(q, 0x141);    // row_half_mirror: the other quad of the 8-lane group
+#undef MK_DPP_ADD
+      const double mean = (double)s * (1.0 / 1024.0);
+      double var = (double)q * (1.0 / 1024.0) - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const float rstd = 1.0f / sqrtf((float)var + p.ln_eps);
+      if ((lane & 7) == 0) prm[wave * 32 + j * 8 + (lane >> 3)] = make_float2(rstd, -(float)mean * rstd);
+    }
+  }
+};
+
+template <int BM, int NT>
+__device__ __forceinline__ void ln_params_to_lds(const GemmParams& p, int m0, int tid, float2* prm) {
+  static_assert(NT == 2 * BM, "two threads per row");
+  const int r = tid >> 1, h = tid & 1;
+  int m = m0 + r;
+  m = m < p.M ? m : p.M - 1;
+  // thread h of the pair takes the lower / upper half of the row's slots: up to 8 independent 8-byte loads in flight
+  // (a loop with one load per iteration serialises on the L2 round trip: measured +3 us per 256x256 tile)
+  const int per = (p.ln_nslot + 1) >> 1;
+  const int lo = h * per, hi = min(p.ln_nslot, lo + per);
+  const float2* st = (const float2*)p.ln_stats + (long long)m * p.ln_nslot;
+  float s = 0.f, q = 0.f;
+  for (int i0 = lo; i0 < hi; i0 += 8) {
+    float2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = i0 + j < hi ? st[i0 + j] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s += v[j].x;
+      q += v[j].y;
+    }
+  }
+  const double sd = (double)s + (double)__shfl_xor(s, 1, 64), qd = (double)q + (double)__shfl_xor(q, 1, 64);
+  const double invn = 1.0 / (64.0 * p.ln_nslot);
+  const double mean = sd * invn;
+  double var = qd * invn - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = 1.0f / sqrtf((float)var + p.ln_eps);
+  if (h == 0) prm[r] = make_float2(rstd, -(float)mean * rstd);
+}
 
 template <typename T>
 __device__ __forceinline__ T to_lp(float v) { return (T)v; }
@@ -135,23 +239,70 @@ struct Stager {
 
 // ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
 // EPI / ACT / HAS_BIAS are compile-time inside the 32x unrolled store loop; epilogue() dispatches once per tile.
-template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS>
+template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS, bool LN = false>
 __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
-                                              int g) {
+                                              int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
   const int fr = lane & 15, fg = lane >> 4;
   const float* bias = HAS_BIAS ? p.bias + (long long)g * p.strideBias_g : nullptr;
   const int nb = n0 + wn * 64 + fg * 4;
-  f32x4 bv[4];
+  f32x4 bv[4], cs[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int n = nb + ni * 16;
     bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[ni] = (LN && n < p.N) ? *(const f32x4*)(p.ln_colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // producer side of the folded LayerNorm (LS_RESIDUAL / PATCH): partial row statistics over this wave's 64 columns
+  const bool emit = (EPI == MK_EPI_LS_RESIDUAL || EPI == MK_EPI_PATCH) && p.xlp_out != nullptr;
 #pragma unroll
   for (int mi = 0; mi < WMF; ++mi) {
     const int m = m0 + wm * (WMF * 16) + mi * 16 + fr;
+    if (emit) {   // no early exit: every lane takes part in the cross-lane sums (invalid rows / columns contribute 0)
+      const bool mok = m < p.M;
+      long long xrow = m;
+      int tok1 = 0;   // PATCH: row of the position table
+      if (EPI == MK_EPI_PATCH) {
+        const int img = m / p.npatch;
+        tok1 = 1 + (m - img * p.npatch);
+        xrow = (long long)img * (p.npatch + 1) + tok1;
+      }
+      float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nb + ni * 16;
+        if (!(mok && n < p.N)) continue;
+        f32x4 v = acc[mi][ni] + bv[ni];
+        float* x = p.out_f32 + xrow * p.ldc + n;
+        if (EPI == MK_EPI_LS_RESIDUAL) {
+          const f32x4 gm = *(const f32x4*)(p.gamma + n);
+          f32x4 r = *(const f32x4*)x;
+          r += gm * v;
+          v = r;
+        } else {
+          v += *(const f32x4*)(p.pos + (long long)tok1 * p.N + n);
+        }
+        *(f32x4*)x = v;
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = to_lp<T>(v[e]);
+          ssum += v[e];
+          qsum += v[e] * v[e];
+        }
+        *(V4*)((T*)p.xlp_out + xrow * p.ldxlp + n) = o;
+      }
+      ssum += __shfl_xor(ssum, 16, 64);
+      qsum += __shfl_xor(qsum, 16, 64);
+      ssum += __shfl_xor(ssum, 32, 64);
+      qsum += __shfl_xor(qsum, 32, 64);
+      if (fg == 0 && mok && n0 + wn * 64 < p.N)
+        ((float2*)p.stats_out)[xrow * p.nslot_out + ((n0 + wn * 64) >> 6)] = make_float2(ssum, qsum);
+      continue;
+    }
     if (m >= p.M) continue;
+    float2 prm = make_float2(1.f, 0.f);
+    if (LN) prm = lnp[wm * (WMF * 16) + mi * 16 + fr];
     int img = 0, tok = 0;
     if (EPI == MK_EPI_QKV) {
       img = m / p.ntok;
@@ -165,7 +316,8 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
       const int n = nb + ni * 16;
       if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
       f32x4 v = acc[mi][ni];
-      if (HAS_BIAS) v += bv[ni];
+      if (LN) v = v * prm.x + (cs[ni] * prm.y + bv[ni]);
+      else if (HAS_BIAS) v += bv[ni];
       if (EPI == MK_EPI_STORE) {
         if (p.resid_lp) {
           const V4 r = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
@@ -220,7 +372,13 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
 
 template <typename T, int WMF>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
-                                         int g) {
+                                         int g, const float2* lnp = nullptr) {
+  if (p.ln_stats) {   // folded LayerNorm (consumer): QKV split, or bias (+ GELU) with a 16-bit output
+    if (p.epi == MK_EPI_QKV) epilogue_impl<T, WMF, MK_EPI_QKV, MK_ACT_NONE, true, true>(p, acc, m0, n0, wm, wn, lane, g, lnp);
+    else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, true, true>(p, acc, m0, n0, wm, wn, lane, g, lnp);
+    else epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_NONE, true, true>(p, acc, m0, n0, wm, wn, lane, g, lnp);
+    return;
+  }
   switch (p.epi) {   // wave-uniform, once per output tile
     case MK_EPI_LS_RESIDUAL: epilogue_impl<T, WMF, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
     case MK_EPI_QKV: epilogue_impl<T, WMF, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, m0, n0, wm, wn, lane, g); break;
@@ -247,9 +405,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
 // only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
 // XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
-template <typename T, int EPI, int ACT, bool HAS_BIAS>
+template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false>
 __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
-                                                  int wn, int lane, int g) {
+                                                  int wn, int lane, int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
   using V8 = typename Lp<T>::V8;
   const int fr = lane & 15, fg = lane >> 4;
@@ -275,12 +433,17 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
       tok = m - img * p.ntok;
     }
   };
-  f32x4 bv[4];
+  f32x4 bv[4], cs[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int n = nw + fg * 4 + ni * 16;
     bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[ni] = (LN && n < p.N) ? *(const f32x4*)(p.ln_colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // folded LayerNorm (consumer): (rstd, -mean * rstd) of this lane's 8 rows, left in LDS by the kernel prologue
+  float2 prm[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) prm[mi] = LN ? lnp[wm * 128 + mi * 16 + fr] : make_float2(1.f, 0.f);
   const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32);
   if (lp_out) {
     int which = 0, head = 0;
@@ -298,7 +461,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           const long long hb = (long long)img * p.heads + head;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
-            const f32x4 v = acc[mi][ni] + bv[ni];
+            const f32x4 v = LN ? acc[mi][ni] * prm[mi].x + (cs[ni] * prm[mi].y + bv[ni]) : acc[mi][ni] + bv[ni];
             T* dst = (T*)p.vt + (hb * 64 + ni * 16 + fg * 4) * p.ntok_pad + vperm(tok);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
@@ -313,7 +476,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 v = acc[mi][ni];
-        if (HAS_BIAS) v += bv[ni];
+        if (LN) v = v * prm[mi].x + (cs[ni] * prm[mi].y + bv[ni]);
+        else if (HAS_BIAS) v += bv[ni];
         if (EPI == MK_EPI_QKV) {
           if (which == 0) v *= p.qscale;
         } else {
@@ -410,21 +574,48 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         }
       }
     };
+    // producer side of the folded LayerNorm: 16-bit copy of the new rows + (sum, sum of squares) over this wave's 64
+    // columns (one DPP row of 16 lanes holds one row segment); all lanes take part, invalid ones contribute zeros
+    const bool emit = (EPI == MK_EPI_LS_RESIDUAL || EPI == MK_EPI_PATCH) && p.xlp_out != nullptr;
+    auto emit_row = [&](long long xrow, int nn, f32x4 x, bool ok) {
+      float ssum = 0.f, qsum = 0.f;
+      if (ok) {
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = to_lp<T>(x[e]);
+          ssum += x[e];
+          qsum += x[e] * x[e];
+        }
+        *(V4*)((T*)p.xlp_out + xrow * p.ldxlp + nn) = o;
+      }
+      ssum = row16_sum(ssum);
+      qsum = row16_sum(qsum);
+      if (ok && c == 0) ((float2*)p.stats_out)[xrow * p.nslot_out + (nw >> 6)] = make_float2(ssum, qsum);
+    };
     auto drain = [&](int half) {
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int r = it * 4 + rr;
         const int m = mw + half * 64 + r;
         const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
-        if (m >= p.M || n >= p.N) continue;
+        const bool ok = m < p.M && n < p.N;
+        if (!ok && !emit) continue;
         if (EPI == MK_EPI_LS_RESIDUAL) {
           f32x4 x = xr[half][it];
           x += gm * val;
-          *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+          if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+          if (emit) emit_row(m, n, x, ok);
         } else if (EPI == MK_EPI_PATCH) {
-          const int img = m / p.npatch, tok = m - img * p.npatch;
-          const f32x4 pe = *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
-          *(f32x4*)(p.out_f32 + ((long long)img * (p.npatch + 1) + 1 + tok) * p.ldc + n) = val + pe;
+          const int mc = ok ? m : 0;
+          const int img = mc / p.npatch, tok = mc - img * p.npatch;
+          const long long xrow = (long long)img * (p.npatch + 1) + 1 + tok;
+          f32x4 x = val;
+          if (ok) {
+            x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+            *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
+          }
+          if (emit) emit_row(xrow, n, x, ok);
         } else {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
         }
@@ -441,7 +632,17 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 
 template <typename T>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
-                                             int lane, int g) {
+                                             int lane, int g, const float2* lnp = nullptr) {
+#if defined(MK_LN_ABL) && MK_LN_ABL == 2
+  if (false) {   // ablation: plain epilogue
+#else
+  if (p.ln_stats) {   // folded LayerNorm (consumer): QKV split, or bias (+ GELU) with a 16-bit output
+#endif
+    if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    return;
+  }
   switch (p.epi) {   // wave-uniform, once per output tile
     case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
     case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;

@@ -203,11 +203,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     mfma32(wf, xf, next2, kt + 2);
   };
 
-  // prologue: stage 0 (own A half + W share) and the own A half of stage 1 (nk >= 2, see launch())
+  // prologue: stage 0 (own A half + W share) and the own A half of stage 1 (nk >= 2, see launch()).
+  // Folded LayerNorm (consumer): the row statistics of the tile are requested first and turned into row parameters in LDS
+  // while the DMA pieces are in flight.
+  const bool ln = AMODE == A_DENSE && p.ln_stats != nullptr;
+#if defined(MK_LN_ABL) && MK_LN_ABL == 1
+  const bool ln_fast = false && ln;   // ablation: no prologue work
+#define MK_LN_NO_SLOW 1
+#else
+  const bool ln_fast = ln && p.ln_nslot == 16;
+#endif
+  LnRowLoads16 lnl;
+  if (ln_fast) lnl.issue(p, m0, tid);
   dma_a(0);
   dma_w(0);
+  if constexpr (A_IN_MFMA_SLOT) dma_a(1);
+  if (ln_fast) lnl.template finish<12>(p, tid, (float2*)(smem + 2 * STAGE_BYTES));   // 12 DMA pieces are younger than the loads
+#ifndef MK_LN_NO_SLOW
+  else if (ln) ln_params_to_lds<256, 512>(p, m0, tid, (float2*)(smem + 2 * STAGE_BYTES));
+#endif
   if constexpr (A_IN_MFMA_SLOT) {
-    dma_a(1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,12 +238,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     stage1(nk - 2, Yes{}, No{});
     stage1(nk - 1, No{}, No{});
   }
-  epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g);
+  epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g, (const float2*)(smem + 2 * STAGE_BYTES));
 }
 
 template <typename T, int AMODE>
 int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
-  constexpr int LDS = 2 * 512 * 128;
+  constexpr int LDS = 2 * 512 * 128 + 256 * 8;   // two stages + the folded LayerNorm's row parameters
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -66,6 +66,43 @@ def gemm_qkv(a, w, bias, q, k, vt, nimg, ntok, ntok_pad, heads):
          heads, qscale, dtype_code(a.dtype), stream())
 
 
+# ---- LayerNorm folded into the GEMMs around it (mickey_hip.h: mk_gemm_*_ln) -------------------------------------------------
+def gemm_ls_residual_ln(a, w, bias, gamma, x, xlp, stats):
+    """x += gamma * (a @ w.T + bias); also xlp = 16-bit copy of the new x, stats[m, N // 64, 2] = per-slot (sum, sum of squares)."""
+    M, K = a.shape
+    N = w.shape[0]
+    call("mk_gemm_ls_residual_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(x), x.stride(0),
+         ptr(xlp), xlp.stride(0), ptr(stats), M, N, K, dtype_code(a.dtype), stream())
+    return x
+
+
+def gemm_patch_embed_ln(a, w, bias, pos, x, xlp, stats, nimg, npatch):
+    D = w.shape[0]
+    call("mk_gemm_patch_embed_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(pos), ptr(x), ptr(xlp), ptr(stats),
+         nimg, npatch, D, w.shape[1], dtype_code(a.dtype), stream())
+
+
+def cls_token_ln(cls, pos, x, xlp, stats, nimg, ntok, D):
+    call("mk_cls_token_ln", ptr(cls), ptr(pos), ptr(x), ptr(xlp), ptr(stats), nimg, ntok, D, dtype_code(xlp.dtype), stream())
+
+
+def gemm_ln(a, w, bias, colsum, stats, eps, act=ACT_NONE, out=None):
+    """out = act(LN(x) @ W.T + b) with a = raw 16-bit rows of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    call("mk_gemm_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps), ptr(out),
+         out.stride(0), M, N, K, act, dtype_code(a.dtype), stream())
+    return out
+
+
+def gemm_qkv_ln(a, w, bias, colsum, stats, eps, q, k, vt, nimg, ntok, ntok_pad, heads):
+    qscale = (64.0 ** -0.5) * LOG2E
+    call("mk_gemm_qkv_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps), ptr(q),
+         ptr(k), ptr(vt), nimg, ntok, ntok_pad, heads, qscale, dtype_code(a.dtype), stream())
+
+
 def im2col_patch14(img, gh, gw, ldo, dtype):
     """img fp32 [nimg, 3, H, W] (any strides with unit innermost) -> [nimg*gh*gw, ldo] lp."""
     assert img.dtype == torch.float32 and img.stride(3) == 1

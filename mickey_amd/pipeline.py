@@ -40,22 +40,40 @@ def encoder_forward(W, ws, img):
     pos = wts_mod.interp_pos_embed(W, gh, gw, dev)
     a = ops.im2col_patch14(img, gh, gw, wts_mod.PATCH_K, lp)
     x = ws.get("x", (M, D), torch.float32, dev)
-    ops.gemm_patch_embed(a, W.patch_w, W.patch_b, pos, x, nimg, npatch)
-    ops.cls_token(W.cls, pos, x, nimg, ntok, D)
-    y = ws.get("y", (M, D), lp, dev)
     att = ws.get("att", (M, D), lp, dev)
     hid = ws.get("hid", (M, 4 * D), lp, dev)
     q = ws.get("q", (nimg, heads, pad, 64), lp, dev, zero=True)   # pad rows stay zero forever
     k = ws.get("k", (nimg, heads, pad, 64), lp, dev, zero=True)
     vt = ws.get("vt", (nimg, heads, 64, pad), lp, dev, zero=True)
-    for blk in W.blocks:
-        ops.layernorm(x, blk.n1w, blk.n1b, 1e-6, out=y)
-        ops.gemm_qkv(y, blk.qkv_w, blk.qkv_b, q, k, vt, nimg, ntok, pad, heads)
-        ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
-        ops.gemm_ls_residual(att, blk.proj_w, blk.proj_b, blk.g1, x)
-        ops.layernorm(x, blk.n2w, blk.n2b, 1e-6, out=y)
-        ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
-        ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
+    if getattr(W, "ln_fold", False):
+        # norm1 / norm2 folded into the GEMMs around them (mickey_hip.h, mk_gemm_*_ln): whoever writes the residual stream
+        # also writes it raw in 16 bit (xs) with per-slot row statistics; qkv / fc1 read xs and normalise in their epilogue
+        xs = ws.get("xs", (M, D), lp, dev)
+        st = ws.get("ln_stats", (M, D // 64, 2), torch.float32, dev)
+        ops.gemm_patch_embed_ln(a, W.patch_w, W.patch_b, pos, x, xs, st, nimg, npatch)
+        ops.cls_token_ln(W.cls, pos, x, xs, st, nimg, ntok, D)
+        last = len(W.blocks) - 1
+        for bi, blk in enumerate(W.blocks):
+            ops.gemm_qkv_ln(xs, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads)
+            ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
+            ops.gemm_ls_residual_ln(att, blk.proj_w, blk.proj_b, blk.g1, x, xs, st)
+            ops.gemm_ln(xs, blk.fc1_wf, blk.fc1_bf, blk.fc1_cs, st, 1e-6, act=ops.ACT_GELU, out=hid)
+            if bi == last:   # nobody consumes the by-products of the last block: the final norm reads the fp32 stream
+                ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
+            else:
+                ops.gemm_ls_residual_ln(hid, blk.fc2_w, blk.fc2_b, blk.g2, x, xs, st)
+    else:
+        ops.gemm_patch_embed(a, W.patch_w, W.patch_b, pos, x, nimg, npatch)
+        ops.cls_token(W.cls, pos, x, nimg, ntok, D)
+        y = ws.get("y", (M, D), lp, dev)
+        for blk in W.blocks:
+            ops.layernorm(x, blk.n1w, blk.n1b, 1e-6, out=y)
+            ops.gemm_qkv(y, blk.qkv_w, blk.qkv_b, q, k, vt, nimg, ntok, pad, heads)
+            ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
+            ops.gemm_ls_residual(att, blk.proj_w, blk.proj_b, blk.g1, x)
+            ops.layernorm(x, blk.n2w, blk.n2b, 1e-6, out=y)
+            ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
+            ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
     feat = ws.get("feat", (nimg * npatch, D), getattr(W, "lp_heads", lp), dev)   # the heads' operand type
     ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1)
     return feat, gh, gw

@@ -46,7 +46,18 @@ def fold_basic_block(sd, p):
     return w1, b1, w2, b2, sc is not None
 
 
-def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=None):
+def fold_layernorm(w, b, ln_w, ln_b, lp_dtype):
+    """LayerNorm folded into the linear layer that consumes it (mickey_hip.h, mk_gemm_ln):
+        LN(x) @ W^T + b  =  rstd * (x @ (W diag(ln_w))^T) - rstd * mean * colsum + (b + W @ ln_b)
+    -> (W' = W diag(ln_w) rounded to the operand type, colsum = row sums of the ROUNDED W' in fp32, b' in fp32)."""
+    w = w.float()
+    wf = (w * ln_w.float()[None, :]).to(lp_dtype)
+    return wf, wf.float().sum(1), b.float() + w @ ln_b.float()
+
+
+def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=None, ln_fold=True):
+    """ln_fold: also prepare norm1 / norm2 folded into qkv / fc1 (16-bit operand types only): the encoder then runs without
+    stand-alone LayerNorm passes (pipeline.encoder_forward)."""
     W = DeviceWeights() if W is None else W
     W.lp = lp_dtype
     dev = device
@@ -60,6 +71,7 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     p = prefix
     D, depth, heads = _arch_from_sd(sd, p)
     W.D, W.depth, W.heads = D, depth, heads
+    W.ln_fold = bool(ln_fold) and lp_dtype != torch.float32 and D % 64 == 0
     wp = torch.zeros((D, PATCH_K))
     wp[:, :588] = sd[p + "patch_embed.proj.weight"].float().reshape(D, 588)
     W.patch_w, W.patch_b = lp(wp), f32(sd[p + "patch_embed.proj.bias"])
@@ -77,6 +89,13 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
         blk.fc1_w, blk.fc1_b = lp(sd[q + "mlp.fc1.weight"]), f32(sd[q + "mlp.fc1.bias"])
         blk.fc2_w, blk.fc2_b = lp(sd[q + "mlp.fc2.weight"]), f32(sd[q + "mlp.fc2.bias"])
         blk.g2 = f32(sd[q + "ls2.gamma"])
+        if W.ln_fold:
+            wf, cs, bf = fold_layernorm(sd[q + "attn.qkv.weight"], sd[q + "attn.qkv.bias"], sd[q + "norm1.weight"],
+                                        sd[q + "norm1.bias"], lp_dtype)
+            blk.qkv_wf, blk.qkv_cs, blk.qkv_bf = lp(wf), f32(cs), f32(bf)
+            wf, cs, bf = fold_layernorm(sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"], sd[q + "norm2.weight"],
+                                        sd[q + "norm2.bias"], lp_dtype)
+            blk.fc1_wf, blk.fc1_cs, blk.fc1_bf = lp(wf), f32(cs), f32(bf)
         W.blocks.append(blk)
     W.norm_w, W.norm_b = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
     W.zero_page = torch.zeros(256, device=dev, dtype=torch.uint8)
@@ -85,10 +104,10 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False):
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False, ln_fold=True):
     """heads_fp32: keep the four head stacks' operands in fp32 (the reference always runs them in fp32,
     mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
-    W = prepare_encoder(sd, device, lp_dtype)
+    W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold)
     dev = device
     W.lp_heads = torch.float32 if heads_fp32 else lp_dtype
 

@@ -125,6 +125,131 @@ def test_patch_embed_and_cls(nimg, H, W, D, tile):
     assert rel(x[:, 0], (cls + pos[0]).expand(nimg, D)) < 1e-7
 
 
+def _slot_stats(x):
+    """(sum, sum of squares) of every row over 64-column slots: what the producer epilogues emit."""
+    M, N = x.shape
+    xs = x.double().reshape(M, N // 64, 64)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [1, 7, 10])
+@pytest.mark.parametrize("M,N,K", [(3878, 1024, 256), (700, 384, 128), (257, 128, 64)])
+def test_ln_fold_producer_residual(M, N, K, tile, dtype):
+    """mk_gemm_ls_residual_ln: x as mk_gemm_ls_residual writes it (bit for bit), its 16-bit copy, and the per-slot row
+    statistics of the NEW x."""
+    from mickey_amd import ops
+    dev = _dev()
+    a = (torch.randn((M, K), generator=g(1)) * 0.5).to(dtype).to(dev)
+    w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).to(dtype).to(dev)
+    bias, gamma = torch.randn((N,), generator=g(3)).to(dev), torch.rand((N,), generator=g(4)).to(dev)
+    x0 = (torch.randn((M, N), generator=g(5)) * 2 + 0.7).to(dev)
+    ops.gemm_set_tile(tile)
+    x_ref = ops.gemm_ls_residual(a, w, bias, gamma, x0.clone())
+    x = x0.clone()
+    xlp = torch.zeros((M, N), device=dev, dtype=dtype)
+    stats = torch.full((M, N // 64, 2), float("nan"), device=dev)
+    ops.gemm_ls_residual_ln(a, w, bias, gamma, x, xlp, stats)
+    assert torch.equal(x, x_ref)
+    assert torch.equal(xlp, x.to(dtype))
+    ref = _slot_stats(x)
+    assert rel(stats[..., 0], ref[..., 0]) < 1e-5 and rel(stats[..., 1], ref[..., 1]) < 1e-5
+    assert bool(torch.isfinite(stats).all())
+
+
+@pytest.mark.parametrize("tile", [0, 7])
+@pytest.mark.parametrize("nimg,H,W,D", [(2, 75, 101, 256), (3, 300, 290, 384)])
+def test_ln_fold_producer_patch_embed_and_cls(nimg, H, W, D, tile):
+    from mickey_amd import ops
+    dev = _dev()
+    ops.gemm_set_tile(tile)
+    gh, gw = H // 14, W // 14
+    ntok = 1 + gh * gw
+    img = torch.rand((nimg, 3, H, W), generator=g(1))
+    w2 = torch.zeros((D, 640))
+    w2[:, :588] = torch.randn((D, 588), generator=g(2)) / math.sqrt(588)
+    w2 = w2.bfloat16().to(dev)
+    bias, pos = (torch.randn((D,), generator=g(3)) * 0.1).to(dev), (torch.randn((ntok, D), generator=g(4)) * 0.1).to(dev)
+    cls = (torch.randn((D,), generator=g(5)) * 0.1).to(dev)
+    a = ops.im2col_patch14(img.to(dev), gh, gw, 640, torch.bfloat16)
+    x_ref = torch.zeros((nimg, ntok, D), device=dev)
+    ops.gemm_patch_embed(a, w2, bias, pos, x_ref, nimg, gh * gw)
+    ops.cls_token(cls, pos, x_ref, nimg, ntok, D)
+    x = torch.zeros((nimg, ntok, D), device=dev)
+    xlp = torch.zeros((nimg * ntok, D), device=dev, dtype=torch.bfloat16)
+    stats = torch.full((nimg * ntok, D // 64, 2), float("nan"), device=dev)
+    ops.gemm_patch_embed_ln(a, w2, bias, pos, x, xlp, stats, nimg, gh * gw)
+    ops.cls_token_ln(cls, pos, x, xlp, stats, nimg, ntok, D)
+    assert torch.equal(x, x_ref)
+    assert torch.equal(xlp, x.reshape(-1, D).bfloat16())
+    ref = _slot_stats(x.reshape(-1, D))
+    assert rel(stats[..., 0], ref[..., 0]) < 1e-5 and rel(stats[..., 1], ref[..., 1]) < 1e-5
+
+
+def _ln_fold_inputs(M, D, N, dtype, dev):
+    """Rows with a mean well away from zero, a spread of scales and a few outlier channels (what DINOv2's residual stream
+    looks like), LayerNorm affine parameters, a linear layer; returns what the host-side fold produces."""
+    x = torch.randn((M, D), generator=g(1)) * (0.5 + 3 * torch.rand((M, 1), generator=g(2))) + 1.5 * torch.randn((M, 1), generator=g(3))
+    x[:, 7] += 40.0
+    x[:, D - 3] -= 25.0
+    lw, lb = 1 + 0.3 * torch.randn((D,), generator=g(4)), 0.2 * torch.randn((D,), generator=g(5))
+    W, b = torch.randn((N, D), generator=g(6)) / math.sqrt(D), torch.randn((N,), generator=g(7)) * 0.1
+    wf = (W * lw).to(dtype)                       # W . diag(ln_weight), rounded once
+    colsum = wf.float().sum(1)
+    bf = b + W @ lb
+    xlp = x.to(dtype)
+    stats = _slot_stats(x).float()
+    mean = x.double().mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-6)
+    # the arithmetic the kernel performs, in fp64 on the same rounded operands
+    y_same = rstd * (xlp.double() @ wf.double().t()) - rstd * mean * colsum.double() + bf.double()
+    # what the reference computes: LayerNorm in fp32, then the linear layer
+    y_true = F.layer_norm(x.double(), (D,), lw.double(), lb.double(), 1e-6) @ W.double().t() + b.double()
+    t = lambda v: v.to(dev)  # noqa: E731
+    return t(xlp), t(wf), t(bf), t(colsum), t(stats), y_same, y_true
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [1, 7, 10])
+@pytest.mark.parametrize("M,D,N,act", [(3878, 1024, 1024, 2), (700, 384, 512, 0), (130, 128, 256, 2)])
+def test_ln_fold_consumer_gemm(M, D, N, act, tile, dtype):
+    """mk_gemm_ln == act(LayerNorm(x) @ W^T + b) with the normalisation applied in the epilogue: exact (fp32 accumulation)
+    against the same formula on the same rounded operands, and at the operand type's noise floor against the fp64 LN."""
+    from mickey_amd import ops
+    dev = _dev()
+    xlp, wf, bf, colsum, stats, y_same, y_true = _ln_fold_inputs(M, D, N, dtype, dev)
+    ops.gemm_set_tile(tile)
+    out = ops.gemm_ln(xlp, wf, bf, colsum, stats, 1e-6, act=act)
+    f = (lambda v: F.gelu(v)) if act == 2 else (lambda v: v)
+    lp_eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel(out.float(), f(y_same)) < 0.6 * lp_eps            # output rounding only
+    e = rel(out.float(), f(y_true))
+    print("ln-fold consumer", dtype, (M, D, N), "vs fp64 LayerNorm + linear: %.2e" % e)
+    assert e < 3 * lp_eps
+
+
+@pytest.mark.parametrize("tile", [1, 7])
+def test_ln_fold_consumer_qkv(tile):
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, ntok, heads = 2, 333, 4
+    D, pad = heads * 64, 384
+    xlp, wf, bf, colsum, stats, y_same, _ = _ln_fold_inputs(nimg * ntok, D, 3 * D, torch.bfloat16, dev)
+    q = torch.zeros((nimg, heads, pad, 64), device=dev, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((nimg, heads, 64, pad), device=dev, dtype=torch.bfloat16)
+    ops.gemm_set_tile(tile)
+    ops.gemm_qkv_ln(xlp, wf, bf, colsum, stats, 1e-6, q, k, vt, nimg, ntok, pad, heads)
+    ref = y_same.reshape(nimg, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    qs = (64.0 ** -0.5) * ops.LOG2E
+    assert rel(q[:, :, :ntok].float(), ref[0] * qs) < 3e-3
+    assert rel(k[:, :, :ntok].float(), ref[1]) < 3e-3
+    t = torch.arange(pad)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    assert rel(vt.cpu().float()[:, :, :, perm][..., :ntok], ref[2].transpose(-1, -2)) < 3e-3
+    assert float(q[:, :, ntok:].abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("D", [128, 384, 1024])
 def test_layernorm(D):
     from mickey_amd import ops
