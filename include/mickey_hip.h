@@ -96,23 +96,28 @@ int mk_im2col_patch14(const float* img, long long stride_img, long long stride_c
 int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int ntok, int D, mk_stream_t stream);
 
 /* ---- LayerNorm folded into the GEMMs around it (the encoder's pre-norm blocks, block.py:84-88,105-106) ----
- * y = LN(x) . W^T + b  ==  rstd_m * (x . (W diag(w_ln))^T) - rstd_m * mean_m * colsum + (b + W . b_ln):  the GEMM that
- * PRODUCES the rows x (patch embedding, cls row, proj / fc2 + LayerScale + residual) also writes them once in 16 bit
- * (raw, un-normalised: the A operand of the next GEMM) together with their partial statistics, and the GEMM that
- * CONSUMES norm1(x) / norm2(x) (qkv, fc1) applies mean / rstd per row in its epilogue.  The 48 stand-alone LayerNorm
- * passes of a ViT-L forward (fp32 read + 16-bit write of the whole token matrix each) disappear; mk_layernorm stays for
- * the final norm and for the exact-fp32 mode.  16-bit dtypes only.
- *   stats  fp32 [rows][N / 64][2]: (sum, sum of squares) of the row over each 64-column slot (deterministic: one
- *          writer per slot, fixed summation order);   xlp  [rows, ldxlp] 16 bit;   N % 64 == 0.
+ * y = LN(x) . W^T + b  ==  rstd_m * (x . (W diag(w_ln))^T) - rstd_m * mean_m * colsum + (b + W . b_ln).
+ * The residual stream x is kept in HBM as TWO 16-bit planes, x = hi + lo with hi = rn16(x), lo = rn16(x - hi): the 4
+ * bytes per element of an fp32 stream, 17 (bf16) / 22 (fp16) mantissa bits -- and hi is, as it stands, the raw A operand
+ * of the next GEMM.  The GEMM that PRODUCES rows of x (patch embedding, cls row, proj / fc2 + LayerScale + residual)
+ * writes hi / lo and the partial row statistics of the fp32 values it rounded; the GEMM that CONSUMES norm1(x) /
+ * norm2(x) (qkv, fc1) reads hi and applies mean / rstd per row in its epilogue.  No stand-alone LayerNorm pass and no
+ * extra copy of the token matrix remain in a block (ViT-L: 48 passes of fp32 read + 16-bit write each); mk_layernorm
+ * stays for the final norm and for the exact-fp32 mode, where x is a plain fp32 matrix.  16-bit dtypes only.
+ *   xh, xl  [rows, ldxs] 16 bit;   stats fp32 [rows][N / 64][2]: (sum, sum of squares) of the row over each 64-column
+ *           slot (deterministic: one writer per slot, fixed summation order);   N % 64 == 0.
+ *   x_f32_out (mk_gemm_ls_residual_ln): if not NULL the updated rows go there as fp32 [M, ldx] and hi / lo / stats are
+ *           left alone -- the last block, whose output feeds the final norm.
  *   colsum fp32 [N]: sum_k W'[n][k] over the 16-bit-ROUNDED folded weights (so that the mean term cancels exactly what
- *          the MFMA accumulates);  bias = b + W . b_ln (fp32, folded on the host);  eps as nn.LayerNorm (1e-6). */
-int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, float* x,
-                           int ldx, void* xlp, int ldxlp, float* stats, int M, int N, int K, int dtype, mk_stream_t stream);
-int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, float* x,
-                           void* xlp, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream);
-int mk_cls_token_ln(const float* cls, const float* pos, float* x, void* xlp, float* stats, int nimg, int ntok, int D, int dtype,
+ *           the MFMA accumulates);  bias = b + W . b_ln (fp32, folded on the host);  eps as nn.LayerNorm (1e-6). */
+int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, void* xh,
+                           void* xl, int ldxs, float* stats, float* x_f32_out, int ldx, int M, int N, int K, int dtype,
+                           mk_stream_t stream);
+int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, void* xh,
+                           void* xl, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream);
+int mk_cls_token_ln(const float* cls, const float* pos, void* xh, void* xl, float* stats, int nimg, int ntok, int D, int dtype,
                     mk_stream_t stream);
-/* consumers: mk_gemm (bias, optional GELU, 16-bit output) and mk_gemm_qkv with A = raw rows [M, K] (lda == K) */
+/* consumers: mk_gemm (bias, optional GELU, 16-bit output) and mk_gemm_qkv with A = the hi plane [M, K] (lda == K) */
 int mk_gemm_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
                float eps, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream);
 int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,

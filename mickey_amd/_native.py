@@ -26,7 +26,7 @@ SIGNATURES = {
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
     "mk_gemm_qkv": ("i", "pipippppiiiifip"),
     "mk_gemm_patch_embed": ("i", "pipipppiiiiip"),
-    "mk_gemm_ls_residual_ln": ("i", "pipipppipipiiiip"),
+    "mk_gemm_ls_residual_ln": ("i", "pipippppippiiiiip"),
     "mk_gemm_patch_embed_ln": ("i", "pipipppppiiiiip"),
     "mk_cls_token_ln": ("i", "pppppiiiip"),
     "mk_gemm_ln": ("i", "pipipppfpiiiiiip"),

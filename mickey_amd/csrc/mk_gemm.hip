@@ -127,7 +127,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
                     (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
-  const bool ln_fold = p.ln_stats || p.xlp_out;
+  const bool ln_fold = p.ln_stats || p.xh;
   if (dtype == MK_F32) {   // exact parity mode: one plain schedule, LayerNorm as its own kernel
     MK_CHECK_ARG(!ln_fold, "gemm: the folded-LayerNorm epilogues exist for 16-bit operands only");
     return launch_f32(p, groups, AMODE, st);
@@ -275,27 +275,29 @@ int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* 
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
-int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, float* x,
-                           int ldx, void* xlp, int ldxlp, float* stats, int M, int N, int K, int dtype, mk_stream_t stream) {
+int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, void* xh,
+                           void* xl, int ldxs, float* stats, float* x_f32_out, int ldx, int M, int N, int K, int dtype,
+                           mk_stream_t stream) {
   GemmParams p = {};
   p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
-  p.epi = MK_EPI_LS_RESIDUAL; p.bias = bias; p.gamma = gamma; p.out_f32 = x; p.ldc = ldx;
-  p.xlp_out = xlp; p.ldxlp = ldxlp; p.stats_out = stats; p.nslot_out = N / 64;
+  p.epi = MK_EPI_LS_RESIDUAL; p.bias = bias; p.gamma = gamma; p.out_f32 = x_f32_out; p.ldc = ldx;
+  p.xh = xh; p.xl = xl; p.ldxs = ldxs; p.stats_out = stats; p.nslot_out = N / 64;
   if (int e = check_common(p, dtype)) return e;
-  MK_CHECK_ARG(bias && gamma && x && lda % 8 == 0 && lda >= K && ldx % 4 == 0 && ldx >= N, "mk_gemm_ls_residual_ln: bad args");
-  MK_CHECK_ARG(xlp && stats && N % 64 == 0 && ldxlp % 8 == 0 && ldxlp >= N, "mk_gemm_ls_residual_ln: xlp / stats / N %% 64");
+  MK_CHECK_ARG(bias && gamma && lda % 8 == 0 && lda >= K, "mk_gemm_ls_residual_ln: bad args");
+  MK_CHECK_ARG(xh && xl && N % 64 == 0 && ldxs % 8 == 0 && ldxs >= N, "mk_gemm_ls_residual_ln: xh / xl / N %% 64");
+  MK_CHECK_ARG(x_f32_out ? (ldx % 4 == 0 && ldx >= N) : stats != nullptr, "mk_gemm_ls_residual_ln: stats, or x_f32_out with ldx");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
-int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, float* x,
-                           void* xlp, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream) {
+int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, void* xh,
+                           void* xl, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream) {
   GemmParams p = {};
   p.A = A; p.W = W; p.M = nimg * npatch; p.N = D; p.K = K; p.lda = lda; p.ldw = ldw;
-  p.epi = MK_EPI_PATCH; p.bias = bias; p.pos = pos; p.npatch = npatch; p.out_f32 = x; p.ldc = D;
-  p.xlp_out = xlp; p.ldxlp = D; p.stats_out = stats; p.nslot_out = D / 64;
+  p.epi = MK_EPI_PATCH; p.bias = bias; p.pos = pos; p.npatch = npatch; p.ldc = D;
+  p.xh = xh; p.xl = xl; p.ldxs = D; p.stats_out = stats; p.nslot_out = D / 64;
   if (int e = check_common(p, dtype)) return e;
-  MK_CHECK_ARG(bias && pos && x && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed_ln: bad args");
-  MK_CHECK_ARG(xlp && stats && D % 64 == 0, "mk_gemm_patch_embed_ln: xlp / stats / D %% 64");
+  MK_CHECK_ARG(bias && pos && lda % 8 == 0 && lda >= K, "mk_gemm_patch_embed_ln: bad args");
+  MK_CHECK_ARG(xh && xl && stats && D % 64 == 0, "mk_gemm_patch_embed_ln: xh / xl / stats / D %% 64");
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 

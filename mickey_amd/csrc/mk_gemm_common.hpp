@@ -44,10 +44,15 @@ struct GemmParams {
   const float* pos;
   int npatch;
   // ---- LayerNorm folded into the GEMMs around it (the encoder's pre-norm blocks) ----
-  // producer side (LS_RESIDUAL / PATCH epilogues): besides the fp32 rows, a 16-bit copy of the NEW rows (the raw, un-
-  // normalised A operand of the next GEMM) and their partial statistics: (sum, sum of squares) per 64-column slot
-  void* xlp_out;          // [rows, ldxlp] 16 bit, indexed like out_f32
-  int ldxlp;
+  // producer side (LS_RESIDUAL / PATCH epilogues with xh set): the residual stream lives in HBM as TWO 16-bit planes,
+  //   x = hi + lo,  hi = rn16(x),  lo = rn16(x - hi)    (17 / 22 mantissa bits for bf16 / fp16 planes),
+  // the same 4 bytes per element as an fp32 stream, but hi IS the raw A operand of the next GEMM: no copy, no LayerNorm
+  // pass.  LS_RESIDUAL reads hi + lo, adds gamma * (acc + bias) in fp32 and writes the new hi / lo plus the per-slot
+  // (sum, sum of squares) of the new fp32 rows; with out_f32 also set it writes the fp32 rows there instead (last block:
+  // the final norm reads fp32).  PATCH writes hi / lo / statistics of the freshly embedded rows.
+  void* xh;
+  void* xl;               // both [rows, ldxs] 16 bit
+  int ldxs;
   float* stats_out;       // [rows][nslot_out][2]
   int nslot_out;          // N / 64
   // consumer side (QKV / STORE epilogues, 16-bit outputs): A = raw rows, W = W.diag(ln_weight) (folded on the host),
@@ -239,7 +244,7 @@ struct Stager {
 
 // ---- epilogue: lane owns row m = ...+(lane&15), features n..n+3 with n = ...+(lane>>4)*4 ----
 // EPI / ACT / HAS_BIAS are compile-time inside the 32x unrolled store loop; epilogue() dispatches once per tile.
-template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS, bool LN = false>
+template <typename T, int WMF, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
                                               int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
@@ -253,12 +258,12 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
     bv[ni] = (HAS_BIAS && n < p.N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     cs[ni] = (LN && n < p.N) ? *(const f32x4*)(p.ln_colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // producer side of the folded LayerNorm (LS_RESIDUAL / PATCH): partial row statistics over this wave's 64 columns
-  const bool emit = (EPI == MK_EPI_LS_RESIDUAL || EPI == MK_EPI_PATCH) && p.xlp_out != nullptr;
+  // producer side of the folded LayerNorm (LS_RESIDUAL / PATCH on the split residual stream)
+  const bool fin = SPLIT && EPI == MK_EPI_LS_RESIDUAL && p.out_f32 != nullptr;   // last block: fp32 rows out, no by-products
 #pragma unroll
   for (int mi = 0; mi < WMF; ++mi) {
     const int m = m0 + wm * (WMF * 16) + mi * 16 + fr;
-    if (emit) {   // no early exit: every lane takes part in the cross-lane sums (invalid rows / columns contribute 0)
+    if (SPLIT) {   // no early exit: every lane takes part in the cross-lane sums (invalid rows / columns contribute 0)
       const bool mok = m < p.M;
       long long xrow = m;
       int tok1 = 0;   // PATCH: row of the position table
@@ -273,30 +278,39 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
         const int n = nb + ni * 16;
         if (!(mok && n < p.N)) continue;
         f32x4 v = acc[mi][ni] + bv[ni];
-        float* x = p.out_f32 + xrow * p.ldc + n;
+        T* ph = (T*)p.xh + xrow * p.ldxs + n;
+        T* pl = (T*)p.xl + xrow * p.ldxs + n;
         if (EPI == MK_EPI_LS_RESIDUAL) {
           const f32x4 gm = *(const f32x4*)(p.gamma + n);
-          f32x4 r = *(const f32x4*)x;
+          const V4 h = *(const V4*)ph, l = *(const V4*)pl;
+          f32x4 r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
           r += gm * v;
           v = r;
         } else {
           v += *(const f32x4*)(p.pos + (long long)tok1 * p.N + n);
         }
-        *(f32x4*)x = v;
-        V4 o;
+        if (fin) {
+          *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = v;
+          continue;
+        }
+        V4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = to_lp<T>(v[e]);
+          oh[e] = to_lp<T>(v[e]);
+          ol[e] = to_lp<T>(v[e] - (float)oh[e]);
           ssum += v[e];
           qsum += v[e] * v[e];
         }
-        *(V4*)((T*)p.xlp_out + xrow * p.ldxlp + n) = o;
+        *(V4*)ph = oh;
+        *(V4*)pl = ol;
       }
       ssum += __shfl_xor(ssum, 16, 64);
       qsum += __shfl_xor(qsum, 16, 64);
       ssum += __shfl_xor(ssum, 32, 64);
       qsum += __shfl_xor(qsum, 32, 64);
-      if (fg == 0 && mok && n0 + wn * 64 < p.N)
+      if (!fin && fg == 0 && mok && n0 + wn * 64 < p.N)
         ((float2*)p.stats_out)[xrow * p.nslot_out + ((n0 + wn * 64) >> 6)] = make_float2(ssum, qsum);
       continue;
     }
@@ -373,6 +387,11 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
 template <typename T, int WMF>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][4], int m0, int n0, int wm, int wn, int lane,
                                          int g, const float2* lnp = nullptr) {
+  if (p.xh) {   // folded LayerNorm (producer): split residual stream
+    if (p.epi == MK_EPI_PATCH) epilogue_impl<T, WMF, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
+    else epilogue_impl<T, WMF, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
+    return;
+  }
   if (p.ln_stats) {   // folded LayerNorm (consumer): QKV split, or bias (+ GELU) with a 16-bit output
     if (p.epi == MK_EPI_QKV) epilogue_impl<T, WMF, MK_EPI_QKV, MK_ACT_NONE, true, true>(p, acc, m0, n0, wm, wn, lane, g, lnp);
     else if (p.act == MK_ACT_GELU) epilogue_impl<T, WMF, MK_EPI_STORE, MK_ACT_GELU, true, true>(p, acc, m0, n0, wm, wn, lane, g, lnp);
@@ -405,7 +424,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
 // only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
 // XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
-template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false>
+template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
                                                   int wn, int lane, int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
@@ -536,13 +555,21 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     // read-modify-write of the residual stream: all 16 loads of a half are issued before anything waits on them (one
     // HBM round trip per half instead of one per row group: measured 0.68 us per dependent load -> 22 us per tile);
     // the second half's loads go out while the first half is still being stored
-    f32x4 xr[2][16];
+    // SPLIT (folded LayerNorm, producer): the stream is two 16-bit planes (x = hi + lo), 8 + 8 bytes per lane and row
+    f32x4 xr[2][SPLIT ? 1 : 16];
+    V4 xh[2][SPLIT ? 16 : 1], xl[2][SPLIT ? 16 : 1];
     auto preload = [&](int half) {
       if (EPI != MK_EPI_LS_RESIDUAL) return;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int m = mw + half * 64 + it * 4 + rr;
-        xr[half][it] = (m < p.M && n < p.N) ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = m < p.M && n < p.N;
+        if (SPLIT) {
+          xh[half][it] = ok ? *(const V4*)((const T*)p.xh + (long long)m * p.ldxs + n) : V4{};
+          xl[half][it] = ok ? *(const V4*)((const T*)p.xl + (long long)m * p.ldxs + n) : V4{};
+        } else {
+          xr[half][it] = ok ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     };
     auto stage = [&](int half) {
@@ -574,20 +601,23 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         }
       }
     };
-    // producer side of the folded LayerNorm: 16-bit copy of the new rows + (sum, sum of squares) over this wave's 64
-    // columns (one DPP row of 16 lanes holds one row segment); all lanes take part, invalid ones contribute zeros
-    const bool emit = (EPI == MK_EPI_LS_RESIDUAL || EPI == MK_EPI_PATCH) && p.xlp_out != nullptr;
-    auto emit_row = [&](long long xrow, int nn, f32x4 x, bool ok) {
+    // producer side of the folded LayerNorm: the new rows as hi / lo planes + (sum, sum of squares) of the fp32 values
+    // over this wave's 64 columns (one DPP row of 16 lanes holds one row segment); all lanes take part, invalid ones
+    // contribute zeros.  fin: last block, fp32 rows out instead.
+    const bool fin = SPLIT && EPI == MK_EPI_LS_RESIDUAL && p.out_f32 != nullptr;
+    auto emit_row = [&](long long xrow, f32x4 x, bool ok) {
       float ssum = 0.f, qsum = 0.f;
       if (ok) {
-        V4 o;
+        V4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = to_lp<T>(x[e]);
+          oh[e] = to_lp<T>(x[e]);
+          ol[e] = to_lp<T>(x[e] - (float)oh[e]);
           ssum += x[e];
           qsum += x[e] * x[e];
         }
-        *(V4*)((T*)p.xlp_out + xrow * p.ldxlp + nn) = o;
+        *(V4*)((T*)p.xh + xrow * p.ldxs + n) = oh;
+        *(V4*)((T*)p.xl + xrow * p.ldxs + n) = ol;
       }
       ssum = row16_sum(ssum);
       qsum = row16_sum(qsum);
@@ -600,22 +630,29 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         const int m = mw + half * 64 + r;
         const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
         const bool ok = m < p.M && n < p.N;
-        if (!ok && !emit) continue;
+        if (!ok && !(SPLIT && !fin)) continue;
         if (EPI == MK_EPI_LS_RESIDUAL) {
-          f32x4 x = xr[half][it];
+          f32x4 x;
+          if (SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (float)xh[half][it][e] + (float)xl[half][it][e];
+          } else {
+            x = xr[half][it];
+          }
           x += gm * val;
-          if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
-          if (emit) emit_row(m, n, x, ok);
+          if (!SPLIT || fin) {
+            if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
+          } else {
+            emit_row(m, x, ok);
+          }
         } else if (EPI == MK_EPI_PATCH) {
           const int mc = ok ? m : 0;
           const int img = mc / p.npatch, tok = mc - img * p.npatch;
           const long long xrow = (long long)img * (p.npatch + 1) + 1 + tok;
           f32x4 x = val;
-          if (ok) {
-            x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
-            *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
-          }
-          if (emit) emit_row(xrow, n, x, ok);
+          if (ok) x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
+          if (SPLIT) emit_row(xrow, x, ok);
+          else if (ok) *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
         } else {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
         }
@@ -633,6 +670,11 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 template <typename T>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
                                              int lane, int g, const float2* lnp = nullptr) {
+  if (p.xh) {   // folded LayerNorm (producer): split residual stream
+    if (p.epi == MK_EPI_PATCH) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+    else epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+    return;
+  }
 #if defined(MK_LN_ABL) && MK_LN_ABL == 2
   if (false) {   // ablation: plain epilogue
 #else

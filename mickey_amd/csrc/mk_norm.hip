@@ -144,17 +144,18 @@ __global__ void cls_kernel(const float* __restrict__ cls, const float* __restric
   x[(long long)im * ntok * D + c] = cls[c] + pos[c];
 }
 
-// CLS row with the folded-LayerNorm by-products: one wave per image; lane l owns columns c = l, l + 64, ...: slot c / 64
-// of the row statistics is a plain wave sum.
+// CLS row of the split residual stream (hi / lo planes) with its slot statistics: one wave per image; lane l owns columns
+// c = l, l + 64, ...: slot c / 64 of the row statistics is a plain wave sum.
 template <typename T>
-__global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
-                                                    T* __restrict__ xlp, float* __restrict__ stats, int ntok, int D) {
+__global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ xh,
+                                                    T* __restrict__ xl, float* __restrict__ stats, int ntok, int D) {
   const int im = blockIdx.x, lane = threadIdx.x;
   const long long row = (long long)im * ntok;
   for (int c0 = 0; c0 < D; c0 += 64) {
     const float v = cls[c0 + lane] + pos[c0 + lane];
-    x[row * D + c0 + lane] = v;
-    xlp[row * D + c0 + lane] = (T)v;
+    const T h = (T)v;
+    xh[row * D + c0 + lane] = h;
+    xl[row * D + c0 + lane] = (T)(v - (float)h);
     const float s = mk::wave_sum(v), q = mk::wave_sum(v * v);
     if (lane == 0) ((float2*)stats)[row * (D / 64) + (c0 >> 6)] = make_float2(s, q);
   }
@@ -227,15 +228,15 @@ int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int nto
   return MK_OK;
 }
 
-/* mk_cls_token + the folded-LayerNorm by-products of the row (16-bit copy, per-slot statistics) */
-int mk_cls_token_ln(const float* cls, const float* pos, float* x, void* xlp, float* stats, int nimg, int ntok, int D, int dtype,
+/* the CLS rows of the split residual stream (hi / lo planes) + their per-slot statistics */
+int mk_cls_token_ln(const float* cls, const float* pos, void* xh, void* xl, float* stats, int nimg, int ntok, int D, int dtype,
                     mk_stream_t stream) {
-  MK_CHECK_ARG(cls && pos && x && xlp && stats && nimg > 0 && ntok > 0 && D > 0 && D % 64 == 0, "mk_cls_token_ln: bad args");
+  MK_CHECK_ARG(cls && pos && xh && xl && stats && nimg > 0 && ntok > 0 && D > 0 && D % 64 == 0, "mk_cls_token_ln: bad args");
   MK_CHECK_ARG(dtype == MK_BF16 || dtype == MK_F16, "mk_cls_token_ln: 16-bit dtypes only");
   if (dtype == MK_BF16)
-    hipLaunchKernelGGL((cls_ln_kernel<__bf16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, x, (__bf16*)xlp, stats, ntok, D);
+    hipLaunchKernelGGL((cls_ln_kernel<__bf16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, (__bf16*)xh, (__bf16*)xl, stats, ntok, D);
   else
-    hipLaunchKernelGGL((cls_ln_kernel<_Float16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, x, (_Float16*)xlp, stats, ntok, D);
+    hipLaunchKernelGGL((cls_ln_kernel<_Float16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, (_Float16*)xh, (_Float16*)xl, stats, ntok, D);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -67,27 +67,28 @@ def gemm_qkv(a, w, bias, q, k, vt, nimg, ntok, ntok_pad, heads):
 
 
 # ---- LayerNorm folded into the GEMMs around it (mickey_hip.h: mk_gemm_*_ln) -------------------------------------------------
-def gemm_ls_residual_ln(a, w, bias, gamma, x, xlp, stats):
-    """x += gamma * (a @ w.T + bias); also xlp = 16-bit copy of the new x, stats[m, N // 64, 2] = per-slot (sum, sum of squares)."""
+def gemm_ls_residual_ln(a, w, bias, gamma, xh, xl, stats, x_out=None):
+    """(xh + xl) += gamma * (a @ w.T + bias) on the split residual stream (two 16-bit planes, x = hi + lo); stats[m, N // 64, 2]
+    receives the per-slot (sum, sum of squares) of the new fp32 rows.  With x_out (fp32 [M, N]) the new rows are written there
+    instead and xh / xl / stats are left alone (last block)."""
     M, K = a.shape
     N = w.shape[0]
-    call("mk_gemm_ls_residual_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(x), x.stride(0),
-         ptr(xlp), xlp.stride(0), ptr(stats), M, N, K, dtype_code(a.dtype), stream())
-    return x
+    call("mk_gemm_ls_residual_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(xh), ptr(xl),
+         xh.stride(0), ptr(stats), ptr(x_out), x_out.stride(0) if x_out is not None else N, M, N, K, dtype_code(a.dtype), stream())
 
 
-def gemm_patch_embed_ln(a, w, bias, pos, x, xlp, stats, nimg, npatch):
+def gemm_patch_embed_ln(a, w, bias, pos, xh, xl, stats, nimg, npatch):
     D = w.shape[0]
-    call("mk_gemm_patch_embed_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(pos), ptr(x), ptr(xlp), ptr(stats),
+    call("mk_gemm_patch_embed_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(pos), ptr(xh), ptr(xl), ptr(stats),
          nimg, npatch, D, w.shape[1], dtype_code(a.dtype), stream())
 
 
-def cls_token_ln(cls, pos, x, xlp, stats, nimg, ntok, D):
-    call("mk_cls_token_ln", ptr(cls), ptr(pos), ptr(x), ptr(xlp), ptr(stats), nimg, ntok, D, dtype_code(xlp.dtype), stream())
+def cls_token_ln(cls, pos, xh, xl, stats, nimg, ntok, D):
+    call("mk_cls_token_ln", ptr(cls), ptr(pos), ptr(xh), ptr(xl), ptr(stats), nimg, ntok, D, dtype_code(xh.dtype), stream())
 
 
 def gemm_ln(a, w, bias, colsum, stats, eps, act=ACT_NONE, out=None):
-    """out = act(LN(x) @ W.T + b) with a = raw 16-bit rows of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host)."""
+    """out = act(LN(x) @ W.T + b) with a = the hi plane of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host)."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:

@@ -46,22 +46,21 @@ def encoder_forward(W, ws, img):
     k = ws.get("k", (nimg, heads, pad, 64), lp, dev, zero=True)
     vt = ws.get("vt", (nimg, heads, 64, pad), lp, dev, zero=True)
     if getattr(W, "ln_fold", False):
-        # norm1 / norm2 folded into the GEMMs around them (mickey_hip.h, mk_gemm_*_ln): whoever writes the residual stream
-        # also writes it raw in 16 bit (xs) with per-slot row statistics; qkv / fc1 read xs and normalise in their epilogue
-        xs = ws.get("xs", (M, D), lp, dev)
+        # norm1 / norm2 folded into the GEMMs around them (mickey_hip.h, mk_gemm_*_ln): the residual stream lives as two
+        # 16-bit planes (x = xh + xl); whoever writes it also writes per-slot row statistics; qkv / fc1 read xh (raw) and
+        # normalise in their epilogue.  The last block writes fp32 rows for the final norm.
+        xh = ws.get("xh", (M, D), lp, dev)
+        xl = ws.get("xl", (M, D), lp, dev)
         st = ws.get("ln_stats", (M, D // 64, 2), torch.float32, dev)
-        ops.gemm_patch_embed_ln(a, W.patch_w, W.patch_b, pos, x, xs, st, nimg, npatch)
-        ops.cls_token_ln(W.cls, pos, x, xs, st, nimg, ntok, D)
+        ops.gemm_patch_embed_ln(a, W.patch_w, W.patch_b, pos, xh, xl, st, nimg, npatch)
+        ops.cls_token_ln(W.cls, pos, xh, xl, st, nimg, ntok, D)
         last = len(W.blocks) - 1
         for bi, blk in enumerate(W.blocks):
-            ops.gemm_qkv_ln(xs, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads)
+            ops.gemm_qkv_ln(xh, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads)
             ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
-            ops.gemm_ls_residual_ln(att, blk.proj_w, blk.proj_b, blk.g1, x, xs, st)
-            ops.gemm_ln(xs, blk.fc1_wf, blk.fc1_bf, blk.fc1_cs, st, 1e-6, act=ops.ACT_GELU, out=hid)
-            if bi == last:   # nobody consumes the by-products of the last block: the final norm reads the fp32 stream
-                ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
-            else:
-                ops.gemm_ls_residual_ln(hid, blk.fc2_w, blk.fc2_b, blk.g2, x, xs, st)
+            ops.gemm_ls_residual_ln(att, blk.proj_w, blk.proj_b, blk.g1, xh, xl, st)
+            ops.gemm_ln(xh, blk.fc1_wf, blk.fc1_bf, blk.fc1_cs, st, 1e-6, act=ops.ACT_GELU, out=hid)
+            ops.gemm_ls_residual_ln(hid, blk.fc2_w, blk.fc2_b, blk.g2, xh, xl, st, x_out=x if bi == last else None)
     else:
         ops.gemm_patch_embed(a, W.patch_w, W.patch_b, pos, x, nimg, npatch)
         ops.cls_token(W.cls, pos, x, nimg, ntok, D)

@@ -132,29 +132,42 @@ def _slot_stats(x):
     return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1)
 
 
+def _split(x, dtype):
+    """fp32 -> the two 16-bit planes of the split residual stream."""
+    hi = x.to(dtype)
+    return hi, (x - hi.float()).to(dtype)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", [1, 7, 10])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 256), (700, 384, 128), (257, 128, 64)])
 def test_ln_fold_producer_residual(M, N, K, tile, dtype):
-    """mk_gemm_ls_residual_ln: x as mk_gemm_ls_residual writes it (bit for bit), its 16-bit copy, and the per-slot row
-    statistics of the NEW x."""
+    """mk_gemm_ls_residual_ln on the split residual stream (x = hi + lo): the new fp32 rows are what mk_gemm_ls_residual
+    computes from hi + lo (bit for bit, checked through the fp32 output form), hi / lo are their two-step rounding, the
+    per-slot statistics are those of the fp32 rows."""
     from mickey_amd import ops
     dev = _dev()
     a = (torch.randn((M, K), generator=g(1)) * 0.5).to(dtype).to(dev)
     w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).to(dtype).to(dev)
     bias, gamma = torch.randn((N,), generator=g(3)).to(dev), torch.rand((N,), generator=g(4)).to(dev)
-    x0 = (torch.randn((M, N), generator=g(5)) * 2 + 0.7).to(dev)
+    hi0, lo0 = _split((torch.randn((M, N), generator=g(5)) * 2 + 0.7).to(dev), dtype)
     ops.gemm_set_tile(tile)
-    x_ref = ops.gemm_ls_residual(a, w, bias, gamma, x0.clone())
-    x = x0.clone()
-    xlp = torch.zeros((M, N), device=dev, dtype=dtype)
+    x_ref = ops.gemm_ls_residual(a, w, bias, gamma, hi0.float() + lo0.float())
+    hi, lo = hi0.clone(), lo0.clone()
     stats = torch.full((M, N // 64, 2), float("nan"), device=dev)
-    ops.gemm_ls_residual_ln(a, w, bias, gamma, x, xlp, stats)
-    assert torch.equal(x, x_ref)
-    assert torch.equal(xlp, x.to(dtype))
-    ref = _slot_stats(x)
+    ops.gemm_ls_residual_ln(a, w, bias, gamma, hi, lo, stats)
+    hr, lr = _split(x_ref, dtype)
+    assert torch.equal(hi, hr) and torch.equal(lo, lr)
+    # the pair carries 2 x the mantissa of one plane
+    assert rel(hi.float() + lo.float(), x_ref) < (2e-5 if dtype == torch.bfloat16 else 5e-7)
+    ref = _slot_stats(x_ref)
     assert rel(stats[..., 0], ref[..., 0]) < 1e-5 and rel(stats[..., 1], ref[..., 1]) < 1e-5
     assert bool(torch.isfinite(stats).all())
+    # last-block form: fp32 rows out, planes and statistics untouched
+    hi2, lo2, st2 = hi0.clone(), lo0.clone(), torch.zeros_like(stats)
+    x_out = torch.zeros((M, N), device=dev)
+    ops.gemm_ls_residual_ln(a, w, bias, gamma, hi2, lo2, st2, x_out=x_out)
+    assert torch.equal(x_out, x_ref) and torch.equal(hi2, hi0) and torch.equal(lo2, lo0) and float(st2.abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("tile", [0, 7])
@@ -175,14 +188,14 @@ def test_ln_fold_producer_patch_embed_and_cls(nimg, H, W, D, tile):
     x_ref = torch.zeros((nimg, ntok, D), device=dev)
     ops.gemm_patch_embed(a, w2, bias, pos, x_ref, nimg, gh * gw)
     ops.cls_token(cls, pos, x_ref, nimg, ntok, D)
-    x = torch.zeros((nimg, ntok, D), device=dev)
-    xlp = torch.zeros((nimg * ntok, D), device=dev, dtype=torch.bfloat16)
+    xh = torch.zeros((nimg * ntok, D), device=dev, dtype=torch.bfloat16)
+    xl = torch.zeros_like(xh)
     stats = torch.full((nimg * ntok, D // 64, 2), float("nan"), device=dev)
-    ops.gemm_patch_embed_ln(a, w2, bias, pos, x, xlp, stats, nimg, gh * gw)
-    ops.cls_token_ln(cls, pos, x, xlp, stats, nimg, ntok, D)
-    assert torch.equal(x, x_ref)
-    assert torch.equal(xlp, x.reshape(-1, D).bfloat16())
-    ref = _slot_stats(x.reshape(-1, D))
+    ops.gemm_patch_embed_ln(a, w2, bias, pos, xh, xl, stats, nimg, gh * gw)
+    ops.cls_token_ln(cls, pos, xh, xl, stats, nimg, ntok, D)
+    hr, lr = _split(x_ref.reshape(-1, D), torch.bfloat16)
+    assert torch.equal(xh, hr) and torch.equal(xl, lr)
+    ref = _slot_stats(x_ref.reshape(-1, D))
     assert rel(stats[..., 0], ref[..., 0]) < 1e-5 and rel(stats[..., 1], ref[..., 1]) < 1e-5
 
 
