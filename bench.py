@@ -233,6 +233,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-h2d", dest="include_h2d", action="store_false", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-single", action="store_true", help="skip the one-pair latency leg reported under 'single_pair'")
     ap.add_argument("--no-ln-fold", action="store_true", help="dev: stand-alone LayerNorm kernels instead of the folded form (A/B)")
+    ap.add_argument("--no-half-rows", action="store_true", help="dev: never pick the 64x128 GEMM tiling automatically (A/B)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
     ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -389,6 +390,8 @@ def main(argv=None):
     from mickey_amd.model import MickeyRelativePose
 
     ops.gemm_set_tile(args.gemm_tile)
+    if args.no_half_rows:
+        ops.gemm_set_tile(500)
     ops.attn_set_mode(args.attn_mode)
 
     def make_model(dtype):

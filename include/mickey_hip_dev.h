@@ -11,9 +11,11 @@ extern "C" {
 #endif
 
 /* Schedule of the GEMM / implicit-GEMM conv kernel: 0 = automatic (128x128 tiles for small problems, the default
- * 256x256 schedule for large ones), 1 = force 128x128 (4 waves, 2 workgroups per CU), 7 = force the 8-wave ping-pong
+ * 256x256 schedule for large ones; 64x128 tiles where 128x128 would leave CUs idle), 1 = force 128x128 (4 waves, 2
+ * workgroups per CU), 2 = force 64x128 (same kernel, half the rows, 3 workgroups per CU), 7 = force the 8-wave ping-pong
  * 256x256 schedule (two waves per SIMD), 10 = force the one-wave-per-SIMD 256x256 schedule (4 waves, 128x128 per wave);
- * 400 + b sets the band height b (in m-tiles) of the 256x256 tile order. */
+ * 400 + b sets the band height b (in m-tiles) of the 256x256 tile order; 500 / 501 switch the automatic use of the 64x128
+ * tiling off / on. */
 int mk_gemm_set_tile(int mode);
 
 /* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave,

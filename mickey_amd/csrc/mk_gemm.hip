@@ -32,14 +32,22 @@ namespace {
 // 128x128 tile, 4 waves (2 x 2, 64x64 per wave), 64 KiB LDS -> 2 workgroups per CU: small / skinny problems (a single
 // image pair, the 128-channel linears of the heads) and the fallback for operands of 2^31 elements or more.
 // Two LDS stages, the LDS-DMA of the next K tile is issued before the MFMAs of the current one, one barrier per K tile.
-template <typename T, int AMODE>
+// WMF = 16-row fragments per wave: 4 -> 128x128 tiles; 2 -> 64x128 tiles (48 KiB of LDS, 3 workgroups per CU) for problems
+// whose 128x128 tiling would leave CUs without work (proj / fc2 of a single image pair: 248 -> 488 workgroups).
+template <typename T, int AMODE, int WMF>
 __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   using V8 = typename Lp<T>::V8;
-  constexpr int WMF = 4, NWM = 2, NWN = 2;
+  constexpr int NWM = 2, NWN = 2;
   constexpr int NW = NWM * NWN, BM = NWM * WMF * 16, BN = NWN * 64;
   constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;          // 1-KiB LDS-DMA pieces per wave per K tile
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile], rows of 128 B
+  // LDS stages.  The 64-row form is what under-filled launches get (one image pair): every workgroup is resident at once
+  // and a launch lasts as long as ONE workgroup's K loop, which with two stages is one L2 -> LDS round trip (~1 us) per
+  // K tile against ~0.15 us of MFMA work (fc2 of one pair: 64 tiles = 65 us).  Three stages keep two DMA stages in
+  // flight behind the one being consumed (72 KiB: two workgroups per CU, i.e. four stages in flight per CU).
+  constexpr int NS = WMF == 2 ? 3 : 2;
+  constexpr int PIECES = AJ + WJ;   // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NS stages][A tile | W tile], rows of 128 B
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -56,21 +64,30 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   Stager<T, AMODE, NW, AJ, WJ> st;
   st.init(p, g, m0, n0, wave, lane);
   st.issue(p, smem, smem + A_BYTES, 0);
+  if (NS == 3 && nk > 1) st.issue(p, smem + STAGE_BYTES, smem + STAGE_BYTES + A_BYTES, 1);
   // folded LayerNorm (consumer): row parameters of the tile into LDS while the first stage is in flight
-  float2* lnp = (float2*)(smem + 2 * STAGE_BYTES);
-  if (AMODE == A_DENSE && p.ln_stats) ln_params_to_lds<BM, NW * 64>(p, m0, tid, lnp);
+  float2* lnp = (float2*)(smem + NS * STAGE_BYTES);
+  if (AMODE == A_DENSE && p.ln_stats && tid < 2 * BM) ln_params_to_lds<BM, 2 * BM>(p, m0, tid, lnp);
   f32x4 acc[WMF][4];
 #pragma unroll
   for (int i = 0; i < WMF; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cur = 0, nxt = NS - 1;   // stage buffers: being consumed / receiving stage kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* nA = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    if (kt + 1 < nk) st.issue(p, nA, nA + A_BYTES, kt + 1);
-    const char* sA = smem + (kt & 1) * STAGE_BYTES;
+    // stage kt has landed; with three stages the pieces of stage kt + 1 (if it exists) may still be in flight
+    if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... for every wave, and everybody is done reading the buffer that is refilled next.  A bare s_barrier: __syncthreads()
+    // is a workgroup fence and makes hipcc drain ALL LDS-DMA traffic (s_waitcnt vmcnt(0)) in front of it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* nA = smem + nxt * STAGE_BYTES;
+    if (kt + NS - 1 < nk) st.issue(p, nA, nA + A_BYTES, kt + NS - 1);
+    const char* sA = smem + cur * STAGE_BYTES;
     const char* sW = sA + A_BYTES;
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       V8 wf[4], xf[WMF];
@@ -93,27 +110,29 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g, lnp);
 }
 
-template <typename T, int AMODE>
+template <typename T, int AMODE, int WMF>
 int launch_small(const GemmParams& p, int groups, hipStream_t st) {
-  constexpr int LDS = 2 * 256 * 128 + 128 * 8;   // two stages + the folded LayerNorm's row parameters
+  constexpr int BM = 32 * WMF;
+  constexpr int LDS = (WMF == 2 ? 3 : 2) * (BM + 128) * 128 + BM * 8;   // the stages + the folded LayerNorm's row parameters
   static bool attr_done = false;  // benign race: the attribute call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  const int ntm = (p.M + 127) / 128, ntn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) / 128;
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
 
 int g_num_cus = 0;
 int g_band_m = 8;      // m-tiles per band of the 256x256 tile order (dev: mk_gemm_set_tile 400 + b)
-int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 7 force the 8-wave ping-pong, 10 force one-wave-per-SIMD
+int g_half_rows = 1;   // automatic choice may use the 64x128 tiling for under-filled launches (dev: 500 off / 501 on)
+int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong, 10 force one-wave-per-SIMD
 
 template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
@@ -138,7 +157,11 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   if (sched == 10 && ln_fold) sched = 7;   // the one-wave-per-SIMD A/B partner has no folded-LayerNorm epilogue
   if (sched == 10) return launch_w4(p, groups, dtype, AMODE, st, g_band_m);
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
-  return dtype == MK_BF16 ? launch_small<__bf16, AMODE>(p, groups, st) : launch_small<_Float16, AMODE>(p, groups, st);
+  // 128x128 tiles fill a 256-CU part (2 workgroups per CU) from 512 tiles on; below that 64-row tiles double the count
+  const long long small_tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * groups;
+  const bool half_rows = g_schedule == 2 || (g_schedule != 1 && g_half_rows && small_tiles < 2 * num_cus() && p.M > 64);
+  if (half_rows) return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 2>(p, groups, st) : launch_small<_Float16, AMODE, 2>(p, groups, st);
+  return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 4>(p, groups, st) : launch_small<_Float16, AMODE, 4>(p, groups, st);
 }
 
 int check_common(const GemmParams& p, int dtype) {
@@ -177,8 +200,12 @@ int mk_gemm_set_tile(int mode) {
     g_band_m = mode - 400 > 0 ? mode - 400 : 1;
     return MK_OK;
   }
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 7 || mode == 10,
-               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 7 8-wave ping-pong, 10 one wave per SIMD)", mode);
+  if (mode == 500 || mode == 501) {   // dev: automatic use of the 64x128 tiling off / on
+    g_half_rows = mode - 500;
+    return MK_OK;
+  }
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7 || mode == 10,
+               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong, 10 one wave per SIMD)", mode);
   g_schedule = mode;
   return MK_OK;
 }

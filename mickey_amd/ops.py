@@ -28,7 +28,8 @@ def preprocess_u8(frames, H, W, out=None):
 
 
 def gemm_set_tile(mode):
-    """Dev knob (mickey_hip_dev.h): 0 auto, 1 force 128x128, 7 force the 8-wave ping-pong, 10 force one wave per SIMD."""
+    """Dev knob (mickey_hip_dev.h): 0 auto, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong, 10 force one wave
+    per SIMD; 500 / 501: automatic use of the 64x128 tiling off / on."""
     call("mk_gemm_set_tile", int(mode))
 
 
