@@ -157,6 +157,32 @@ __device__ __forceinline__ void ln_params_to_lds(const GemmParams& p, int m0, in
 template <typename T>
 __device__ __forceinline__ T to_lp(float v) { return (T)v; }
 
+// four 16-bit values <-> two dwords, by hand: arrays of bf16x4 / f16x4 kept live across a wait made hipcc keep every
+// element in its own VGPR (the split-stream epilogue then spilled the accumulators of EVERY tile to scratch: +25 % on all
+// GEMM launches).  As raw dwords the 32 pre-loaded chunks of a wave are 64 + 64 registers, like the fp32 form.
+template <typename T>
+__device__ __forceinline__ f32x4 unpack4(uint2 u);
+template <>
+__device__ __forceinline__ f32x4 unpack4<__bf16>(uint2 u) {
+  return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+               __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+template <>
+__device__ __forceinline__ f32x4 unpack4<_Float16>(uint2 u) {
+  const f16x4 h = __builtin_bit_cast(f16x4, u);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <>
+__device__ __forceinline__ f32x4 unpack4<float>(uint2) { return f32x4{0.f, 0.f, 0.f, 0.f}; }   // fp32 mode has no split stream
+template <typename T>
+__device__ __forceinline__ uint2 pack4(f32x4 v) {
+  typename Lp<T>::V4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+  if constexpr (sizeof(T) == 2) return __builtin_bit_cast(uint2, o);
+  else return uint2{0u, 0u};
+}
+
 // swap bits 2 and 3 of a token index: the V^T image is stored key-permuted so that the 8 keys a lane
 // owns after the 32x32 S^T MFMA are one contiguous 16-B chunk (see mk_attention.hip)
 __device__ __forceinline__ int vperm(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
@@ -424,7 +450,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
 // only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
 // XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
-template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false>
+// SPLIT (split residual stream, §2.1b of DESIGN.md) is instantiated for INTERIOR tiles only (no row / column predicates:
+// straight-line code; with per-row branches this variant pushed the whole kernel over 256 VGPRs and hipcc spilled half the
+// accumulators of every tile of every launch) -- edge tiles take the direct epilogue; FIN: fp32 rows out (last block).
+template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false, bool FIN = false>
 __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
                                                   int wn, int lane, int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
@@ -552,21 +581,39 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     const int n = nw + c * 4;
     f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f};
     if (EPI == MK_EPI_LS_RESIDUAL && n < p.N) gm = *(const f32x4*)(p.gamma + n);
+    // split stream: the bias is added in the drain layout (a lane's column quad is fixed there: 4 registers instead of the
+    // 16 of the accumulator layout; same operation order, bit-identical) -- this variant runs at the 256-register limit
+    f32x4 bvd = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (SPLIT && HAS_BIAS && n < p.N) bvd = *(const f32x4*)(bias + n);
     // read-modify-write of the residual stream: all 16 loads of a half are issued before anything waits on them (one
     // HBM round trip per half instead of one per row group: measured 0.68 us per dependent load -> 22 us per tile);
     // the second half's loads go out while the first half is still being stored
     // SPLIT (folded LayerNorm, producer): the stream is two 16-bit planes (x = hi + lo), 8 + 8 bytes per lane and row
     f32x4 xr[2][SPLIT ? 1 : 16];
-    V4 xh[2][SPLIT ? 16 : 1], xl[2][SPLIT ? 16 : 1];
-    auto preload = [&](int half) {
+    uint2 xh[2][SPLIT ? 16 : 1], xl[2][SPLIT ? 16 : 1];
+    // split planes: wave-uniform row base (SGPRs) + one 32-bit per-lane element offset, so that the 64 loads and 64 stores
+    // of a wave share ONE address register (kept as 64-bit per-lane addresses they pushed the kernel over 256 VGPRs and
+    // hipcc spilled the accumulators of every tile)
+    const unsigned lane_off = (unsigned)rr * (unsigned)p.ldxs + (unsigned)n;
+    // the same offset, opaque to the optimiser, for the stores: otherwise hipcc keeps the 64 per-lane 64-bit addresses of
+    // the loads alive for the stores to the same places (128 registers, most of them spilled) instead of re-deriving each
+    // from the scalar row base with one v_lshl_add_u64
+    unsigned lane_off_st = lane_off;
+    asm volatile("" : "+v"(lane_off_st));
+    auto plane_row = [&](void* plane, int half, int it) -> T* {   // uniform part: first row of the 4-row group
+      return (T*)plane + (long long)(mw + half * 64 + it * 4) * p.ldxs;
+    };
+    // it0 / it1: range of 4-row groups of the half (the split variant works in quarters, see the end of the function)
+    auto preload = [&](int half, int it0 = 0, int it1 = 16) {
       if (EPI != MK_EPI_LS_RESIDUAL) return;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
+        if (it < it0 || it >= it1) continue;
         const int m = mw + half * 64 + it * 4 + rr;
-        const bool ok = m < p.M && n < p.N;
+        const bool ok = SPLIT || (m < p.M && n < p.N);
         if (SPLIT) {
-          xh[half][it] = ok ? *(const V4*)((const T*)p.xh + (long long)m * p.ldxs + n) : V4{};
-          xl[half][it] = ok ? *(const V4*)((const T*)p.xl + (long long)m * p.ldxs + n) : V4{};
+          xh[half][it] = ok ? *(const uint2*)(plane_row(p.xh, half, it) + lane_off) : uint2{0u, 0u};
+          xl[half][it] = ok ? *(const uint2*)(plane_row(p.xl, half, it) + lane_off) : uint2{0u, 0u};
         } else {
           xr[half][it] = ok ? *(const f32x4*)(p.out_f32 + (long long)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -579,7 +626,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           f32x4 v = acc[half * 4 + mi][ni];
-          if (HAS_BIAS) v += bv[ni];
+          if (HAS_BIAS && !SPLIT) v += bv[ni];
           if (EPI == MK_EPI_STORE) {
             if (p.resid_lp) {
               const int m = mw + half * 64 + r, nn = nw + fg * 4 + ni * 16;
@@ -604,38 +651,38 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     // producer side of the folded LayerNorm: the new rows as hi / lo planes + (sum, sum of squares) of the fp32 values
     // over this wave's 64 columns (one DPP row of 16 lanes holds one row segment); all lanes take part, invalid ones
     // contribute zeros.  fin: last block, fp32 rows out instead.
-    const bool fin = SPLIT && EPI == MK_EPI_LS_RESIDUAL && p.out_f32 != nullptr;
-    auto emit_row = [&](long long xrow, f32x4 x, bool ok) {
+    constexpr bool fin = FIN;
+    auto emit_row = [&](long long xrow, T* dh, T* dl, f32x4 x, bool ok) {
       float ssum = 0.f, qsum = 0.f;
       if (ok) {
-        V4 oh, ol;
+        const uint2 oh = pack4<T>(x);
+        const uint2 ol = pack4<T>(x - unpack4<T>(oh));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          oh[e] = to_lp<T>(x[e]);
-          ol[e] = to_lp<T>(x[e] - (float)oh[e]);
           ssum += x[e];
           qsum += x[e] * x[e];
         }
-        *(V4*)((T*)p.xh + xrow * p.ldxs + n) = oh;
-        *(V4*)((T*)p.xl + xrow * p.ldxs + n) = ol;
+        *(uint2*)dh = oh;
+        *(uint2*)dl = ol;
       }
       ssum = row16_sum(ssum);
       qsum = row16_sum(qsum);
       if (ok && c == 0) ((float2*)p.stats_out)[xrow * p.nslot_out + (nw >> 6)] = make_float2(ssum, qsum);
     };
-    auto drain = [&](int half) {
+    auto drain = [&](int half, int it0 = 0, int it1 = 16) {
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
+        if (it < it0 || it >= it1) continue;
         const int r = it * 4 + rr;
         const int m = mw + half * 64 + r;
-        const f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
-        const bool ok = m < p.M && n < p.N;
-        if (!ok && !(SPLIT && !fin)) continue;
+        f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
+        if (SPLIT) val += bvd;
+        const bool ok = SPLIT || (m < p.M && n < p.N);   // SPLIT: interior tiles only
+        if (!ok) continue;
         if (EPI == MK_EPI_LS_RESIDUAL) {
           f32x4 x;
           if (SPLIT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = (float)xh[half][it][e] + (float)xl[half][it][e];
+            x = unpack4<T>(xh[half][it]) + unpack4<T>(xl[half][it]);
           } else {
             x = xr[half][it];
           }
@@ -643,7 +690,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           if (!SPLIT || fin) {
             if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
           } else {
-            emit_row(m, x, ok);
+            emit_row(m, plane_row(p.xh, half, it) + lane_off_st, plane_row(p.xl, half, it) + lane_off_st, x, ok);
           }
         } else if (EPI == MK_EPI_PATCH) {
           const int mc = ok ? m : 0;
@@ -651,54 +698,78 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           const long long xrow = (long long)img * (p.npatch + 1) + 1 + tok;
           f32x4 x = val;
           if (ok) x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
-          if (SPLIT) emit_row(xrow, x, ok);
+          if (SPLIT) emit_row(xrow, (T*)p.xh + xrow * p.ldxs + n, (T*)p.xl + xrow * p.ldxs + n, x, ok);
           else if (ok) *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
         } else {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
         }
       }
     };
-    preload(0);
-    stage(0);
-    preload(1);
-    drain(0);
-    stage(1);
-    drain(1);
+    if (SPLIT && !FIN && EPI == MK_EPI_LS_RESIDUAL) {
+      // the variant that also splits, sums and DPP-reduces what it stores: with both halves pre-loaded (128 registers
+      // next to the 64 accumulators still waiting) hipcc spilled.  Quarters, two of them in flight (64 registers):
+      // every load still has at least one quarter of draining to land.
+      preload(0, 0, 16);
+      stage(0);
+      drain(0, 0, 8);
+      preload(1, 0, 8);
+      drain(0, 8, 16);
+      preload(1, 8, 16);
+      stage(1);
+      drain(1, 0, 8);
+      drain(1, 8, 16);
+    } else {
+      preload(0);
+      stage(0);
+      preload(1);
+      drain(0);
+      stage(1);
+      drain(1);
+    }
   }
 }
 
-template <typename T>
+// KIND selects which epilogues a kernel instantiation carries.  All epilogues of an instantiation are inlined into ONE
+// register allocation: a rarely taken variant that needs more registers than the rest makes hipcc spill the accumulators of
+// every tile of every launch (measured: +25 % on all GEMMs of the forward when the split-stream epilogue shared the kernel
+// with the plain ones).  0 = the plain epilogues, 1 = folded-LayerNorm consumer (QKV / bias (+GELU) with row parameters),
+// 2 = folded-LayerNorm producer (split residual stream), 3 = the same writing fp32 rows (last block): 2 and 3 together in
+// one kernel spill again.
+template <typename T, int KIND>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
                                              int lane, int g, const float2* lnp = nullptr) {
-  if (p.xh) {   // folded LayerNorm (producer): split residual stream
-    if (p.epi == MK_EPI_PATCH) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-    else epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-    return;
-  }
-#if defined(MK_LN_ABL) && MK_LN_ABL == 2
-  if (false) {   // ablation: plain epilogue
-#else
-  if (p.ln_stats) {   // folded LayerNorm (consumer): QKV split, or bias (+ GELU) with a 16-bit output
-#endif
+  if constexpr (KIND == 2 || KIND == 3) {
+    const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;   // workgroup-uniform
+    if (KIND == 3) {   // LS_RESIDUAL with fp32 rows out (last block)
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
+    } else if (p.epi == MK_EPI_PATCH) {
+      if (interior) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      else epilogue_impl<T, 8, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
+    } else {
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
+    }
+  } else if constexpr (KIND == 1) {
     if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
     else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
     else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
-    return;
-  }
-  switch (p.epi) {   // wave-uniform, once per output tile
-    case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
-    case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
-    case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
-    default:
-      if (!p.bias) {
-        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-      } else {
-        if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-        else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-        else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-      }
+  } else {
+    switch (p.epi) {   // wave-uniform, once per output tile
+      case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+      case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+      case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+      default:
+        if (!p.bias) {
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        } else {
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+        }
+    }
   }
 }
 

@@ -20,7 +20,7 @@ namespace {
 //     W(kt+1) is issued in row g's L(kt,0) slot (the last reader of W(kt-1), row 1 in slot 4kt-1, is behind);
 //   * every DMA has 3-5 slots to land; once per stage a counted vmcnt at the end of slot 4kt+3 (row 0: 4 newer DMAs
 //     may stay in flight; row 1: 0) precedes the barrier that opens stage kt+1.
-template <typename T, int AMODE>
+template <typename T, int AMODE, int KIND>
 __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
   using V8 = typename Lp<T>::V8;
   constexpr int WMF = 8, BM = 256, BN = 256;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // prologue: stage 0 (own A half + W share) and the own A half of stage 1 (nk >= 2, see launch()).
   // Folded LayerNorm (consumer): the row statistics of the tile are requested first and turned into row parameters in LDS
   // while the DMA pieces are in flight.
-  const bool ln = AMODE == A_DENSE && p.ln_stats != nullptr;
+  const bool ln = KIND == 1 && p.ln_stats != nullptr;
 #if defined(MK_LN_ABL) && MK_LN_ABL == 1
   const bool ln_fast = false && ln;   // ablation: no prologue work
 #define MK_LN_NO_SLOW 1
@@ -238,15 +238,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     stage1(nk - 2, Yes{}, No{});
     stage1(nk - 1, No{}, No{});
   }
-  epilogue_lds<T>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g, (const float2*)(smem + 2 * STAGE_BYTES));
+  epilogue_lds<T, KIND>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g, (const float2*)(smem + 2 * STAGE_BYTES));
 }
 
-template <typename T, int AMODE>
-int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
+template <typename T, int AMODE, int KIND>
+int launch_k(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   constexpr int LDS = 2 * 512 * 128 + 256 * 8;   // two stages + the folded LayerNorm's row parameters
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -254,17 +254,24 @@ int launch_t(const GemmParams& p, int groups, hipStream_t st, int band_m) {
     attr_done = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p, band_m);
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p, band_m);
   MK_CHECK_LAUNCH();
   return MK_OK;
+}
+
+template <typename T>
+int launch_dense(const GemmParams& p, int groups, hipStream_t st, int band_m) {
+  if (p.xh && p.epi == MK_EPI_LS_RESIDUAL && p.out_f32) return launch_k<T, A_DENSE, 3>(p, groups, st, band_m);
+  if (p.xh) return launch_k<T, A_DENSE, 2>(p, groups, st, band_m);
+  if (p.ln_stats) return launch_k<T, A_DENSE, 1>(p, groups, st, band_m);
+  return launch_k<T, A_DENSE, 0>(p, groups, st, band_m);
 }
 
 }  // namespace
 
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m) {
-  if (amode == A_DENSE)
-    return dtype == MK_BF16 ? launch_t<__bf16, A_DENSE>(p, groups, st, band_m) : launch_t<_Float16, A_DENSE>(p, groups, st, band_m);
-  return dtype == MK_BF16 ? launch_t<__bf16, A_CONV3>(p, groups, st, band_m) : launch_t<_Float16, A_CONV3>(p, groups, st, band_m);
+  if (amode == A_DENSE) return dtype == MK_BF16 ? launch_dense<__bf16>(p, groups, st, band_m) : launch_dense<_Float16>(p, groups, st, band_m);
+  return dtype == MK_BF16 ? launch_k<__bf16, A_CONV3, 0>(p, groups, st, band_m) : launch_k<_Float16, A_CONV3, 0>(p, groups, st, band_m);
 }
 
 }  // namespace gemm
