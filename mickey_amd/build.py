@@ -8,7 +8,9 @@ box (it is git-ignored, not gpurun-ignored).
 """
 import concurrent.futures
 import glob
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -27,6 +29,52 @@ EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fa
                "mk_gemm_pp64.hip": (["-DMK_LN_ABL=%s" % os.environ["MK_LN_ABL"]] if os.environ.get("MK_LN_ABL") else []),
                "mk_gemm.hip": (["-DMK_PP64_ABLATIONS"] if os.environ.get("MK_PP64_ABLATIONS") else []) +
                               (["-DMK_GEMM_ABLATIONS"] if os.environ.get("MK_GEMM_ABLATIONS") else [])}
+
+
+USAGE_JSON = os.path.join(OBJDIR, "resource_usage.json")
+_REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|"
+                     r"Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|Dynamic Stack):\s+(\S+)")
+
+
+def _load_usage():
+    try:
+        with open(USAGE_JSON) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _parse_resource_remarks(out):
+    """-> ([{name, sgprs, vgprs, agprs, scratch, sgpr_spill, vgpr_spill, occupancy}], the compiler output without the remarks)"""
+    kernels, rest, skip = [], [], 0
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "Occupancy [waves/SIMD]": "occupancy"}
+    for line in out.splitlines():
+        m = _REMARK.search(line)
+        if m and "kernel-resource-usage" in line:
+            k, v = m.group(1), m.group(2)
+            if k == "Function Name":
+                kernels.append({"name": v})
+                skip = 2   # the two source-context lines clang prints under the first remark of a kernel
+            elif k in keys and kernels:
+                kernels[-1][keys[k]] = int(v)
+            continue
+        if skip and (line.lstrip().startswith("|") or re.match(r"\s*\d+ \|", line)):
+            skip -= 1
+            continue
+        rest.append(line)
+    return kernels, "\n".join(rest)
+
+
+def resource_usage(ensure=True):
+    """{source file: [per-kernel register / scratch / spill figures]} of the current build; with ensure, sources that have no
+    entry yet (objects built before this report existed) are recompiled."""
+    usage = _load_usage()
+    srcs = [os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))]
+    if ensure and any(s not in usage for s in srcs):
+        build(force=True, verbose=False)
+        usage = _load_usage()
+    return usage
 
 
 def hipcc():
@@ -53,7 +101,10 @@ def build(force=False, save_temps=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_time = _newest(hdrs) if hdrs else 0.0
     cc = hipcc()
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+    # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch / spills, parsed into build/resource_usage.json
+    # (tests/test_host_cpu.py asserts that no hot kernel spills: one register-hungry epilogue variant inlined into the GEMM
+    # kernel once made hipcc spill the accumulators of every tile of every launch, +25 % on all GEMMs)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage",
              "-I", INCLUDE]
     jobs = []
     objs = []
@@ -72,13 +123,20 @@ def build(force=False, save_temps=False, verbose=True):
         return s, r.returncode, r.stdout
 
     failed = False
+    usage = _load_usage()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for s, rc, out in ex.map(run, jobs):
             if verbose:
                 print("[hipcc] %s -> %s" % (os.path.basename(s), "ok" if rc == 0 else "FAILED"))
+            kernels, out = _parse_resource_remarks(out)
+            if rc == 0:
+                usage[os.path.basename(s)] = kernels
             if out.strip() and (rc != 0 or verbose):
                 print(out)
             failed |= rc != 0
+    if jobs:
+        with open(USAGE_JSON, "w") as f:
+            json.dump(usage, f, indent=1, sort_keys=True)
     if failed:
         raise RuntimeError("hipcc failed")
     lib = lib_path()

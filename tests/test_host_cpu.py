@@ -141,3 +141,47 @@ def test_intrinsics_rescale_matches_the_reference_formula():
     img = np.full((7, 9, 3), 37, np.uint8)
     assert np.array_equal(IO.resize_bilinear(img, 9, 7), img.astype(np.float32))
     assert np.allclose(IO.resize_bilinear(img, 20, 15), 37.0)
+
+
+def test_no_product_kernel_spills_registers():
+    """Per-kernel register report of the build (hipcc -Rpass-analysis=kernel-resource-usage -> build/resource_usage.json).
+    All epilogues of a GEMM kernel share ONE register allocation: a variant over 256 VGPRs makes hipcc spill the
+    accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward).
+    Development-only schedules (the one-wave-per-SIMD GEMM, the pinned-interleave attention) are exempt."""
+    from mickey_amd import build as B
+    usage = B.resource_usage()
+    dev_only = ("gemm_w4_kernel", "attn_fwd_lp_kernel")
+    seen = 0
+    for src, kernels in usage.items():
+        for k in kernels:
+            if any(d in k["name"] for d in dev_only):
+                continue
+            seen += 1
+            # (SGPR spills go to spare VGPR lanes, not to memory: several kernels have a few, they are not asserted on)
+            assert k.get("vgpr_spill", 0) == 0, (src, k)
+            assert k.get("scratch", 0) <= 32, (src, k)   # 32 B: the V^T element-store path of the qkv epilogue
+    assert seen > 50 and any("gemm_pp64_kernel" in k["name"] for k in usage.get("mk_gemm_pp64.hip", []))
+
+
+def test_fold_layernorm_is_an_identity():
+    """weights.fold_layernorm: LN(x) @ W^T + b == rstd * (x @ W'^T) - rstd * mean * colsum + b' (what mk_gemm_ln evaluates),
+    checked with un-rounded folded weights; with the 16-bit rounding of W' the difference stays at that rounding."""
+    import torch
+    import torch.nn.functional as F
+    from mickey_amd import weights
+    g = torch.Generator().manual_seed(3)
+    M, D, N = 40, 128, 96
+    x = (torch.randn((M, D), generator=g) * 2 + 1.3).double()
+    x[:, 5] += 30
+    lw, lb = (1 + 0.3 * torch.randn((D,), generator=g)).double(), (0.2 * torch.randn((D,), generator=g)).double()
+    W, b = (torch.randn((N, D), generator=g) / D ** 0.5).double(), torch.randn((N,), generator=g).double()
+    ref = F.layer_norm(x, (D,), lw, lb, 1e-6) @ W.t() + b
+    mean = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+    wf, cs, bf = weights.fold_layernorm(W, b, lw, lb, torch.float64)
+    out = rstd * (x @ wf.t()) - rstd * mean * cs + bf
+    assert float((out - ref).abs().max()) < 1e-5   # the fold itself works in fp32
+    wf16, cs16, bf16 = weights.fold_layernorm(W.float(), b.float(), lw.float(), lb.float(), torch.bfloat16)
+    assert wf16.dtype == torch.bfloat16 and torch.equal(cs16, wf16.float().sum(1))   # colsum of the ROUNDED weights
+    out16 = rstd * (x @ wf16.double().t()) - rstd * mean * cs16.double() + bf16.double()
+    assert float((out16 - ref).norm() / ref.norm()) < 2 ** -8
