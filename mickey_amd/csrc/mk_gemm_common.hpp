@@ -63,6 +63,24 @@ struct GemmParams {
   float ln_eps;
 };
 
+// Row statistics of the folded LayerNorm, ONE summation order in every epilogue (so that a row's statistics -- hence its
+// normalisation, hence every bit downstream -- do not depend on which schedule, tile or tile position produced it: the
+// batch-invariance tests compare pair i of a 32-pair forward with a 1-pair forward bit for bit).  A 64-column slot is 16
+// column quads q = 0..15 (columns 4q..4q+3):  quad sum sequentially, squares by fma;  then the tree
+//   (q, q^1), (.., q^2)  ->  Q_j = sum of quads 4j..4j+3;   then (Q0 + Q1) + (Q2 + Q3).
+// LDS epilogue: lane c of a 16-lane DPP row holds quad c  -> quad_stats + row16_sum (quad_perm, quad_perm, half mirror, mirror).
+// direct epilogue: lane (fr, fg) holds quads fg + 4 ni, ni = 0..3 of its row -> quad_stats per ni, lane ^ 16, lane ^ 32, then in-lane.
+__device__ __forceinline__ void quad_stats(const f32x4& x, float& s, float& q) {
+  s = x[0];
+  s += x[1];
+  s += x[2];
+  s += x[3];
+  q = __builtin_fmaf(x[0], x[0], 0.0f);
+  q = __builtin_fmaf(x[1], x[1], q);
+  q = __builtin_fmaf(x[2], x[2], q);
+  q = __builtin_fmaf(x[3], x[3], q);
+}
+
 // 16-lane (one DPP row) all-reduce: every lane of the row ends up with the same sum
 __device__ __forceinline__ float row16_sum(float v) {
 #define MK_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
@@ -298,7 +316,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
         tok1 = 1 + (m - img * p.npatch);
         xrow = (long long)img * (p.npatch + 1) + tok1;
       }
-      float ssum = 0.f, qsum = 0.f;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // per column quad fg + 4 ni (see quad_stats)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int n = nb + ni * 16;
@@ -326,16 +344,19 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
         for (int e = 0; e < 4; ++e) {
           oh[e] = to_lp<T>(v[e]);
           ol[e] = to_lp<T>(v[e] - (float)oh[e]);
-          ssum += v[e];
-          qsum += v[e] * v[e];
         }
+        quad_stats(v, s4[ni], q4[ni]);
         *(V4*)ph = oh;
         *(V4*)pl = ol;
       }
-      ssum += __shfl_xor(ssum, 16, 64);
-      qsum += __shfl_xor(qsum, 16, 64);
-      ssum += __shfl_xor(ssum, 32, 64);
-      qsum += __shfl_xor(qsum, 32, 64);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {   // (q, q^1) then (.., q^2): quads fg^1, fg^2 of the same ni live in lane^16, lane^32
+        s4[ni] += __shfl_xor(s4[ni], 16, 64);
+        q4[ni] += __shfl_xor(q4[ni], 16, 64);
+        s4[ni] += __shfl_xor(s4[ni], 32, 64);
+        q4[ni] += __shfl_xor(q4[ni], 32, 64);
+      }
+      const float ssum = (s4[0] + s4[1]) + (s4[2] + s4[3]), qsum = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       if (!fin && fg == 0 && mok && n0 + wn * 64 < p.N)
         ((float2*)p.stats_out)[xrow * p.nslot_out + ((n0 + wn * 64) >> 6)] = make_float2(ssum, qsum);
       continue;
@@ -657,11 +678,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
       if (ok) {
         const uint2 oh = pack4<T>(x);
         const uint2 ol = pack4<T>(x - unpack4<T>(oh));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ssum += x[e];
-          qsum += x[e] * x[e];
-        }
+        quad_stats(x, ssum, qsum);
         *(uint2*)dh = oh;
         *(uint2*)dl = ol;
       }

@@ -163,6 +163,19 @@ def test_ln_fold_producer_residual(M, N, K, tile, dtype):
     ref = _slot_stats(x_ref)
     assert rel(stats[..., 0], ref[..., 0]) < 1e-5 and rel(stats[..., 1], ref[..., 1]) < 1e-5
     assert bool(torch.isfinite(stats).all())
+    # one summation order in every epilogue (quad_stats in mk_gemm_common.hpp): the statistics of a row do not depend on the
+    # schedule, the tile shape or where in a tile the row sits -- which is what keeps pair i of a 32-pair batch bit-identical
+    # to the same pair run alone
+    ops.gemm_set_tile(1)
+    hi1, lo1, st1 = hi0.clone(), lo0.clone(), torch.zeros_like(stats)
+    ops.gemm_ls_residual_ln(a, w, bias, gamma, hi1, lo1, st1)
+    assert torch.equal(st1, stats) and torch.equal(hi1, hi) and torch.equal(lo1, lo)
+    if M > 300:   # the same rows at another tile alignment (first 37 rows dropped)
+        hi3, lo3, st3 = hi0[37:].clone(), lo0[37:].clone(), torch.zeros_like(stats[37:])
+        ops.gemm_set_tile(tile)
+        ops.gemm_ls_residual_ln(a[37:].contiguous(), w, bias, gamma, hi3, lo3, st3)
+        assert torch.equal(st3, stats[37:]) and torch.equal(hi3, hi[37:])
+    ops.gemm_set_tile(tile)
     # last-block form: fp32 rows out, planes and statistics untouched
     hi2, lo2, st2 = hi0.clone(), lo0.clone(), torch.zeros_like(stats)
     x_out = torch.zeros((M, N), device=dev)
