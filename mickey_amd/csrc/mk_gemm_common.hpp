@@ -768,9 +768,14 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     }
   } else if constexpr (KIND == 1) {
-    if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
-    else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
-    else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+#if defined(MK_LN_ABL) && MK_LN_ABL == 2
+    constexpr bool LNE = false;   // timing ablation (wrong results): prologue only, plain epilogue arithmetic
+#else
+    constexpr bool LNE = true;
+#endif
+    if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
   } else {
     switch (p.epi) {   // wave-uniform, once per output tile
       case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
