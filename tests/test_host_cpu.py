@@ -185,3 +185,50 @@ def test_fold_layernorm_is_an_identity():
     assert wf16.dtype == torch.bfloat16 and torch.equal(cs16, wf16.float().sum(1))   # colsum of the ROUNDED weights
     out16 = rstd * (x @ wf16.double().t()) - rstd * mean * cs16.double() + bf16.double()
     assert float((out16 - ref).norm() / ref.norm()) < 2 ** -8
+
+
+def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
+    """pipeline.encoder_forward wiring on CPU with recording stand-ins for the kernels: with the LayerNorm fold the block is
+    qkv_ln -> attention -> residual_ln -> gemm_ln(GELU) -> residual_ln, fed from the split stream, the LAST residual GEMM
+    writes fp32 rows for the final norm and no LayerNorm kernel runs inside a block; without it the plain sequence."""
+    import torch
+    from mickey_amd import ops, pipeline, synthetic as syn, weights
+    calls = []
+
+    def rec(name, ret=None):
+        def f(*a, **k):
+            calls.append((name, a, k))
+            return ret(*a, **k) if callable(ret) else ret
+        return f
+
+    def im2col(img, gh, gw, ldo, dtype):
+        calls.append(("im2col", (), {}))
+        return torch.zeros((img.shape[0] * gh * gw, ldo), dtype=dtype)
+
+    for nm in ("gemm_patch_embed", "cls_token", "gemm_qkv", "flash_attn", "gemm_ls_residual", "gemm", "gemm_patch_embed_ln",
+               "cls_token_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_ln"):
+        monkeypatch.setattr(ops, nm, rec(nm))
+    monkeypatch.setattr(ops, "im2col_patch14", im2col)
+    monkeypatch.setattr(ops, "layernorm", rec("layernorm", lambda x, w, b, eps, out=None, **k: out))
+    sd = syn.dinov2_state_dict("vit_tiny_test", seed=1)
+    img = torch.rand((2, 3, 84, 126))
+    for fold in (True, False):
+        W = weights.prepare_encoder(sd, torch.device("cpu"), torch.bfloat16, prefix="", ln_fold=fold)
+        assert W.ln_fold == fold and hasattr(W.blocks[0], "qkv_wf") == fold
+        calls.clear()
+        feat, gh, gw = pipeline.encoder_forward(W, pipeline.Workspace(), img)
+        names = [c[0] for c in calls]
+        assert (gh, gw) == (6, 9) and feat.shape == (2 * 54, 128)
+        if fold:
+            assert names == ["im2col", "gemm_patch_embed_ln", "cls_token_ln"] + \
+                ["gemm_qkv_ln", "flash_attn", "gemm_ls_residual_ln", "gemm_ln", "gemm_ls_residual_ln"] * W.depth + ["layernorm"]
+            res = [c for c in calls if c[0] == "gemm_ls_residual_ln"]
+            assert [c[2].get("x_out") is not None for c in res] == [False] * (2 * W.depth - 1) + [True]
+            xh = calls[1][1][4]
+            assert all(c[1][0] is xh for c in calls if c[0] in ("gemm_qkv_ln", "gemm_ln"))    # consumers read the hi plane
+            assert calls[-1][1][0] is res[-1][2]["x_out"]                                     # the final norm reads the fp32 rows
+        else:
+            assert names == ["im2col", "gemm_patch_embed", "cls_token"] + \
+                ["layernorm", "gemm_qkv", "flash_attn", "gemm_ls_residual", "layernorm", "gemm", "gemm_ls_residual"] * W.depth + ["layernorm"]
+    # fp32 operands never fold (the exact parity mode keeps LayerNorm as its own kernel)
+    assert not weights.prepare_encoder(sd, torch.device("cpu"), torch.float32, prefix="", ln_fold=True).ln_fold
