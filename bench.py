@@ -446,8 +446,15 @@ def main(argv=None):
                         "algorithmic_bytes_per_launch": 1.403e9 * B / 32.0, "launches": g["launches"],
                         "avg_launch_ms": g["ms"] / g["launches"], "avg_launch_gflop": g["work"] / g["launches"] / 1e9,
                         "stages": stages}
+                notes = []
+                if getattr(model, "ln_fold", False) and model.lp_dtype != torch.float32:
+                    notes.append("the encoder GEMM epilogues carry the folded LayerNorm (statistics, normalisation, split "
+                                 "residual stream): 48 LayerNorm passes per forward are gone from the 'layernorm' stage and "
+                                 "their remaining cost is inside this time (--no-ln-fold for the A/B)")
                 if graphed:
-                    roof["note"] = "forward replayed as a hipGraph in the timed region; kernel events from one extra eager step"
+                    notes.append("forward replayed as a hipGraph in the timed region; kernel events from one extra eager step")
+                if notes:
+                    roof["note"] = "; ".join(notes)
         out = {
             "metric": "image pairs/sec (540x720)", "value": world * B * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
