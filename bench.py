@@ -17,7 +17,11 @@ Rank 0 prints ONE JSON line (contract in the task statement) with
                   sampler against their governing peak; hypotheses / refinement: time only)
   cpu_baseline -- the CPU oracle (torch-CPU fp32 restatement of the reference) timed on this box's host
                   cores on a bounded sample (1 pair; 1 warm-up + median of 3, per stage), N = 1 only
-  alt          -- the same workload with fp16 operands (the reference's own low-precision mode), short run
+  legs         -- the same forward at the other precisions / configurations BASELINE.json and the reference name:
+                  fp16 operands (the reference's shipped low-precision mode), ref_split (fp16 encoder + fp32 heads: the
+                  reference's exact precision split, mickey_extractor.py:49-56), vit_small (the encoder north_star names),
+                  config5 (1280x720, Sinkhorn matcher, fp16); each a full timed run with its own dominant-stage roofline
+  sustained    -- the headline configuration again over 60 steps (clocks settled at the socket power limit)
 """
 import argparse
 import json
@@ -33,22 +37,29 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
-TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.json"
 
 
-def pmc_traffic_bytes(batch):
+def pmc_traffic(batch):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of THIS workload
-    (TRAFFIC_SOURCE, produced by tools/pmc_bench_traffic.sh; FETCH_SIZE doubled as the gfx950 note in
-    MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads).  Counters cannot be collected from inside the
-    timed run, so the figure is a constant read from that file and only reported for the batch size it was measured at."""
+    (TRAFFIC_SOURCE, produced by tools/profile_round.sh; FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md
+    prescribes for 16-B/lane streaming reads).  Counters cannot be collected from inside the timed run, so the figure is
+    read from that file -- and only reported when the file was taken from the SAME kernel sources (build.source_hash())
+    and batch size as this run; otherwise traffic is null."""
+    from mickey_amd import build as mkbuild
     path = os.path.join(ROOT, TRAFFIC_SOURCE)
-    if batch != 32 or not os.path.exists(path):
-        return None
+    if not os.path.exists(path):
+        return None, "no %s" % TRAFFIC_SOURCE
     d = json.load(open(path))
+    if d.get("source_hash") != mkbuild.source_hash():
+        return None, "%s was collected from other kernel sources (%s != %s)" % (TRAFFIC_SOURCE, d.get("source_hash"), mkbuild.source_hash())
+    if d.get("batch") != batch:
+        return None, "%s was collected at batch %s" % (TRAFFIC_SOURCE, d.get("batch"))
     try:
-        return (2.0 * d["FETCH_SIZE"]["gemm_dense_256"]["mean_KiB"] + d["WRITE_SIZE"]["gemm_dense_256"]["mean_KiB"]) * 1024.0
-    except KeyError:
-        return None
+        g = d["encoder_gemm"]
+        return (2.0 * g["FETCH_SIZE_KiB_per_launch"] + g["WRITE_SIZE_KiB_per_launch"]) * 1024.0, None
+    except KeyError as e:
+        return None, "%s lacks %s" % (TRAFFIC_SOURCE, e)
 
 
 class StageProfiler:
@@ -70,7 +81,7 @@ class StageProfiler:
         import torch
         prof = self
 
-        def timed(name, stage, work_of):
+        def timed(name, stage, work_of, bytes_of=None):
             fn = getattr(ops, name)
 
             def inner(*a, **k):
@@ -80,18 +91,35 @@ class StageProfiler:
                 e0.record()
                 out = fn(*a, **k)
                 e1.record()
-                prof.records.append((stage, float(work_of(*a, **k)), e0, e1))
+                prof.records.append((stage, float(work_of(*a, **k)), e0, e1, float(bytes_of(*a, **k)) if bytes_of else 0.0))
                 return out
             setattr(ops, name, inner)
 
         esz = lambda t: t.element_size()  # noqa: E731
         mnk = lambda a, w, *r, **k: 2.0 * a.shape[0] * w.shape[0] * w.shape[1]  # noqa: E731
-        timed("gemm", "encoder_gemm", mnk)
-        timed("gemm_ls_residual", "encoder_gemm", mnk)
-        timed("gemm_qkv", "encoder_gemm", mnk)
-        timed("gemm_patch_embed", "encoder_gemm", mnk)
-        for nm in ("gemm_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_patch_embed_ln"):   # LayerNorm folded in
-            timed(nm, "encoder_gemm", mnk)
+        # ALGORITHMIC bytes of one encoder-GEMM launch, from the shapes and plane widths actually passed: A and W read once,
+        # the output written once, plus what the fused epilogue moves (fp32 residual read-modify-write, or the two 16-bit
+        # planes of the split stream read + written, and the per-slot row statistics block written / read)
+        opnd = lambda a, w: a.shape[0] * w.shape[1] * esz(a) + w.shape[0] * w.shape[1] * esz(w)  # noqa: E731
+        stat = lambda M, D: M * (D // 64) * 8  # noqa: E731
+
+        def b_gemm(a, w, bias=None, act=0, out_f32=False, out=None, **k):
+            return opnd(a, w) + a.shape[0] * w.shape[0] * (esz(out) if out is not None else (4 if out_f32 else esz(a)))
+        timed("gemm", "encoder_gemm", mnk, b_gemm)
+        timed("gemm_ls_residual", "encoder_gemm", mnk, lambda a, w, bias, gamma, x: opnd(a, w) + 8 * x.numel())
+        timed("gemm_qkv", "encoder_gemm", mnk, lambda a, w, *r, **k: opnd(a, w) + a.shape[0] * w.shape[0] * esz(a))
+        timed("gemm_patch_embed", "encoder_gemm", mnk,
+              lambda a, w, bias, pos, x, nimg, npatch: opnd(a, w) + a.shape[0] * w.shape[0] * 4 + pos.numel() * 4)
+        # LayerNorm folded in
+        timed("gemm_ln", "encoder_gemm", mnk, lambda a, w, bias, colsum, stats, eps, act=0, out=None:
+              opnd(a, w) + a.shape[0] * w.shape[0] * esz(a) + stat(a.shape[0], w.shape[1]))
+        timed("gemm_qkv_ln", "encoder_gemm", mnk, lambda a, w, bias, colsum, stats, *r, **k:
+              opnd(a, w) + a.shape[0] * w.shape[0] * esz(a) + stat(a.shape[0], w.shape[1]))
+        timed("gemm_ls_residual_ln", "encoder_gemm", mnk, lambda a, w, bias, gamma, xh, xl, stats, x_out=None:
+              opnd(a, w) + 2 * esz(xh) * xh.numel() + (4 * xh.numel() if x_out is not None else
+                                                      2 * esz(xh) * xh.numel() + stat(a.shape[0], w.shape[0])))
+        timed("gemm_patch_embed_ln", "encoder_gemm", mnk, lambda a, w, bias, pos, xh, xl, stats, nimg, npatch:
+              opnd(a, w) + a.shape[0] * w.shape[0] * 2 * esz(xh) + pos.numel() * 4 + stat(a.shape[0], w.shape[0]))
         # attention.py:53-59: per (image, head) QK^T and PV, 2 * 2 * N^2 * 64
         timed("flash_attn", "attention", lambda q, k, vt, out, nimg, heads, ntok, pad: 4.0 * nimg * heads * ntok * ntok * 64)
         # implicit-GEMM 3x3 conv: 2 * M * Cout * (9 C1 + C2) per group
@@ -124,10 +152,11 @@ class StageProfiler:
 
     def summary(self, steps):
         by = {}
-        for stage, work, e0, e1 in self.records:
-            d = by.setdefault(stage, {"launches": 0, "work": 0.0, "ms": 0.0})
+        for stage, work, e0, e1, nbytes in self.records:
+            d = by.setdefault(stage, {"launches": 0, "work": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["work"] += work
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         total_ms = sum(d["ms"] for d in by.values()) or 1.0
         out = []
@@ -195,6 +224,8 @@ def cpu_baseline(cfg, sd):
     runs = [one(True) for _ in range(3)]
     med = {k: sorted(r[k] for r in runs)[1] for k in runs[0]}
     return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "kind": "port",
+            "pinned_by": "tests/test_oracle_golden.py (the oracle vs the reference's own outputs, tests/golden/*.npz, regenerated "
+                         "from /root/reference by oracle/make_golden.py in test_committed_fixtures_reproduce_from_the_reference)",
             "protocol": "1 warm-up + median of 3", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
             "sample": "1 pair 540x720, full forward (ViT-L fp32 + heads + dual-softmax + 20x100 RANSAC), torch-CPU "
                       "oracle, median %.2f s per pair" % med["total"]}
@@ -226,7 +257,11 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the short fp16 run reported under 'alt'")
+    ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the vit_small and config5 legs")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step sustained leg")
+    ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no sustained / PCIe / "
+                                                         "single-pair / CPU legs (profiling passes)")
     ap.add_argument("--include-h2d", action="store_true", default=True,
                     help="also report the PCIe-inclusive rate under 'pcie_inclusive' (default at N=1): uint8 frames from host "
                          "memory through the input pipeline (pinned ring, H2D, resize kernel) into the forward; never `value`")
@@ -238,12 +273,18 @@ def parse_args(argv=None):
     ap.add_argument("--attn-mode", type=int, default=0, help="dev: mk_attn_set_mode mode (0 = default)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="hipGraph replay of the forward (auto: batches of <= 4 pairs, where launches dominate)")
+    ap.add_argument("--dump-poses", default=None, help="TEST HOOK (tests/test_rccl_gpu.py): torch.save the poses of the last "
+                                                        "timed step (the gathered ones under torch.distributed.run) to this path")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend ('nccl' is RCCL on ROCm)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST HOOK (tests/test_bench_cpu.py): CPU tensors and a trivial stand-in model, so that the launcher, "
                          "sharding, gather and timing logic of --gpus N can be exercised under gloo without a GPU; "
                          "the printed line is marked \"stub\": true and is not a measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.lean:
+        args.no_alt = args.no_legs = args.no_sustained = args.no_single = args.no_cpu_baseline = True
+        args.include_h2d = False
+    return args
 
 
 def resolve_world(args, env, device_count):
@@ -364,6 +405,32 @@ def main_stub(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def roofline_entry(stages, by, B, dtype, model):
+    """The `roofline` object of the JSON line: the dominant kernel (the encoder GEMM) + the per-stage list."""
+    g = by.get("encoder_gemm")
+    if not g:
+        return None
+    tf = g["work"] / (g["ms"] * 1e-3) / 1e12
+    traffic, why = pmc_traffic(B)
+    roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2, patch embed)" % dtype,
+            "achieved": tf, "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TF,
+            "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss side, PMC)",
+            "traffic_source": (TRAFFIC_SOURCE + " (committed rocprofv3 --pmc passes of this workload at the same kernel "
+                               "sources; a constant, not measured in this run)") if traffic is not None else why,
+            "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+            "algorithmic_bytes_note": "from the shapes and plane widths of the launches of the timed region (A, W, outputs, "
+                                      "residual planes, row-statistics blocks), averaged over the launch mix",
+            "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
+            "avg_launch_gflop": g["work"] / g["launches"] / 1e9, "stages": stages}
+    if getattr(model, "ln_fold", False):
+        import torch
+        if model.lp_dtype != torch.float32:
+            roof["note"] = ("the encoder GEMM epilogues carry the folded LayerNorm (statistics, normalisation, split residual "
+                            "stream): 48 LayerNorm passes per forward are gone from the 'layernorm' stage and their remaining "
+                            "cost is inside this time (--no-ln-fold for the A/B)")
+    return roof
+
+
 def main(argv=None):
     args = parse_args(argv)
     import torch
@@ -394,25 +461,31 @@ def main(argv=None):
         ops.gemm_set_tile(500)
     ops.attn_set_mode(args.attn_mode)
 
-    def make_model(dtype):
+    def make_model(dtype, heads_fp32=False, arch="vit_large", matcher=None):
         cfg = default_cfg()
         cfg["AMD"]["ENCODER_DTYPE"] = dtype
+        cfg["AMD"]["HEADS_DTYPE"] = "fp32" if heads_fp32 else "same"
         cfg["AMD"]["SEED"] = rank
         cfg["AMD"]["LN_FOLD"] = not args.no_ln_fold
         cfg["AMD"]["GRAPH"] = {"auto": "auto", "on": True, "off": False}[args.graph]
-        sd = syn.mickey_state_dict(cfg, seed=0)
+        cfg["AMD"]["VIT"] = arch
+        cfg["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = syn.VIT_ARCH[arch][0]
+        if matcher:
+            cfg["FEATURE_MATCHER"]["TYPE"] = matcher
+        sd = syn.mickey_state_dict(cfg, seed=0, arch=arch)
         m = MickeyRelativePose(cfg)
         m.load_state_dict(sd)
         return m.to(dev), cfg, sd
+
+    prof = None
+    if not args.no_kernel_events:
+        prof = StageProfiler()
+        prof.wrap(ops)
 
     model, cfg, sd = make_model(args.dtype)
     B = args.batch
     batch = syn.synthetic_batch(B=B, H=H, W=W, seed=1234 + 2 * rank)
     data0 = {k: v.to(dev) for k, v in batch.items()}
-    prof = None
-    if not args.no_kernel_events:
-        prof = StageProfiler()
-        prof.wrap(ops)
     gatherer = D.PoseGatherer(dev) if use_dist else None
 
     dt, last, poses = measure(model, data0, args, use_dist, world, gatherer, prof)
@@ -429,32 +502,19 @@ def main(argv=None):
     if use_dist:
         assert poses is not None and poses[0].shape[0] == world * B, "gathered poses do not cover the global batch"
     ok = bool(torch.isfinite(last["R"]).all())
+    if args.dump_poses and rank == 0:
+        src = poses if poses is not None else (last["R"], last["t"], last["inliers"])
+        torch.save({"R": src[0].cpu(), "t": src[1].cpu(), "inliers": src[2].cpu()}, args.dump_poses)
 
     out = None
     if rank == 0:
         roof = None
         if prof is not None and prof.records:
             stages, by = prof.summary(ev_steps)
-            g = by.get("encoder_gemm")
-            if g:
-                tf = g["work"] / (g["ms"] * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2, patch embed)" % args.dtype,
-                        "achieved": tf, "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TF,
-                        "traffic": pmc_traffic_bytes(B), "traffic_unit": "bytes/launch (L2-miss side, PMC)",
-                        "traffic_source": TRAFFIC_SOURCE + " (committed rocprofv3 --pmc passes of this workload; a constant, "
-                                          "not measured in this run)",
-                        "algorithmic_bytes_per_launch": 1.403e9 * B / 32.0, "launches": g["launches"],
-                        "avg_launch_ms": g["ms"] / g["launches"], "avg_launch_gflop": g["work"] / g["launches"] / 1e9,
-                        "stages": stages}
-                notes = []
-                if getattr(model, "ln_fold", False) and model.lp_dtype != torch.float32:
-                    notes.append("the encoder GEMM epilogues carry the folded LayerNorm (statistics, normalisation, split "
-                                 "residual stream): 48 LayerNorm passes per forward are gone from the 'layernorm' stage and "
-                                 "their remaining cost is inside this time (--no-ln-fold for the A/B)")
-                if graphed:
-                    notes.append("forward replayed as a hipGraph in the timed region; kernel events from one extra eager step")
-                if notes:
-                    roof["note"] = "; ".join(notes)
+            roof = roofline_entry(stages, by, B, args.dtype, model)
+            if roof is not None and graphed:
+                roof["note"] = (roof.get("note", "") + "; forward replayed as a hipGraph in the timed region; kernel events "
+                                "from one extra eager step").lstrip("; ")
         out = {
             "metric": "image pairs/sec (540x720)", "value": world * B * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -468,17 +528,58 @@ def main(argv=None):
             "roofline": roof,
             "finite_output": ok,
         }
-    if not args.no_alt and args.dtype == "bf16" and not use_dist:
-        del model
+
+    single = rank == 0 and not use_dist
+    if single and not args.no_sustained:
+        # the headline configuration over 60 steps: the part runs at its socket power limit and the clock it sustains
+        # settles below what a 20-step region sees (round 1: -3 %)
+        a3 = argparse.Namespace(**vars(args))
+        a3.steps, a3.warmup = 60, 0
+        dts, _, _ = measure(model, data0, a3, False, 1, None, None)
+        out["sustained"] = {"value": B * a3.steps / dts, "unit": "pairs/s", "steps": a3.steps, "ms_per_step": dts / a3.steps * 1e3,
+                            "what": "same model / batch / dtype, 60 back-to-back steps straight after the timed region"}
+    del model
+    torch.cuda.empty_cache()
+
+    def leg(name, what, dtype, steps, warmup, batch_pairs=None, hw=(H, W), dominant="encoder_gemm", **mk):
+        """One more full timed run (same measure(): barrier-free at N = 1, synchronize on both sides) of another
+        precision / configuration, with its own per-stage roofline list."""
+        bp = batch_pairs or B
+        m, _, _ = make_model(dtype, **mk)
+        d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=bp, H=hw[0], W=hw[1], seed=1234).items()}
+        a = argparse.Namespace(**vars(args))
+        a.steps, a.warmup = steps, warmup
+        if prof is not None:
+            prof.records = []
+        dtl, lastl, _ = measure(m, d, a, False, 1, None, prof)
+        ent = {"what": what, "dtype": dtype, "value": bp * steps / dtl, "unit": "pairs/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": dtl / steps * 1e3, "pairs_per_step": bp, "image_hw": list(hw),
+               "finite_output": bool(torch.isfinite(lastl["R"]).all())}
+        if prof is not None and prof.records and not len(m._graphs):
+            st, _ = prof.summary(steps)
+            ent["stages"] = [{k: s[k] for k in ("stage", "bound", "ms_per_step", "achieved", "peak", "unit", "frac") if k in s} for s in st]
+            dom = [s for s in st if s["stage"] == dominant]
+            if dom:
+                ent["roofline"] = {k: dom[0][k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac")}
+        del m, d
         torch.cuda.empty_cache()
-        m16, _, _ = make_model("fp16")
-        a2 = argparse.Namespace(**vars(args))
-        a2.steps, a2.warmup = max(2, min(args.steps, 3)), 1
-        dt16, _, _ = measure(m16, data0, a2, False, 1, None, None)
-        out["alt"] = {"dtype": "fp16", "value": B * a2.steps / dt16, "unit": "pairs/s", "steps": a2.steps,
-                      "note": "fp16 operands are the reference's own low-precision mode (MICKEY.DINOV2.FLOAT16)"}
-        del m16
-    if rank == 0 and not use_dist and (args.include_h2d or not args.no_single):
+        out.setdefault("legs", {})[name] = ent
+
+    if single and not args.no_alt and args.dtype == "bf16":
+        leg("fp16", "fp16 operands everywhere: the reference's shipped low-precision mode for the encoder "
+            "(MICKEY.DINOV2.FLOAT16), heads in fp16 too", "fp16", args.steps, args.warmup)
+        leg("ref_split", "fp16 encoder + fp32 heads (fp32 MFMA): the reference's exact precision split "
+            "(mickey_extractor.py:49-56)", "fp16", max(3, args.steps // 4), 1, heads_fp32=True)
+        out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
+                      "note": "= legs.fp16 (kept for readers of the round-2 line)"}
+    if single and not args.no_legs:
+        leg("vit_small", "DINOv2 ViT-S/14 encoder (the size north_star names; 305 GFLOP per pair, attention 46 %% of it) "
+            "+ the same heads / matcher / solver, %d pairs of 540x720" % B, args.dtype, max(5, args.steps // 2), 2,
+            arch="vit_small", dominant="attention")
+        leg("config5", "BASELINE.json configs[4]: 8 pairs of 1280x720 (51x91 grid, n = 4641), Sinkhorn matcher (10 "
+            "iterations; governed by HBM: 20 LSE passes over the (n+1)^2 fp32 coupling matrix = 301 MB per pair at 540x720, "
+            "1.72 GB here), fp16 operands", "fp16", 3, 1, batch_pairs=8, hw=(720, 1280), dominant="matcher", matcher="Sinkhorn")
+    if single and (args.include_h2d or not args.no_single):
         m2 = make_model(args.dtype)[0]
         if args.include_h2d:
             from mickey_amd import input_pipeline as ip

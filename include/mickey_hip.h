@@ -193,10 +193,11 @@ int mk_head_tails(const float* feat_det, const float* w_score, const float* feat
  *   dsc0 [B, C, n0], dsc1 [B, C, n1] fp32;  scr0 [B, n0], scr1 [B, n1] fp32 (may be NULL with kp/final NULL)
  *   scores / kp_scores / final_scores [B, n0, n1] fp32, each may be NULL (lean mode).
  *   use_dustbin: append the scalar `dustbin` as extra row/column/corner before both softmaxes.
- *   work: fp32 scratch, mk_dual_softmax_work_floats(B, n0, n1) elements, 16-byte aligned (softmax partials + one
- *          [B, n0, n1] copy of the scaled correlation; the copy lives in `scores` / `final_scores` instead when one of
- *          them is requested, so that part of `work` is touched only when neither is). */
-long long mk_dual_softmax_work_floats(int B, int n0, int n1);
+ *   work: fp32 scratch, mk_dual_softmax_work_floats(B, n0, n1, own_copy) elements, 16-byte aligned: the softmax partials,
+ *          plus -- with own_copy != 0 -- one [B, n0, n1] copy of the scaled correlation.  The copy lives in `scores` /
+ *          `final_scores` when one of them is requested: pass own_copy = 1 only for a call with scores == final_scores ==
+ *          NULL (kp_scores alone). */
+long long mk_dual_softmax_work_floats(int B, int n0, int n1, int own_copy);
 int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
                     int use_dustbin, float dustbin, float* scores, float* kp_scores, float* final_scores, float* work, int B,
                     int C, int n0, int n1, mk_stream_t stream);

@@ -13,15 +13,16 @@ extern "C" {
 /* Schedule of the GEMM / implicit-GEMM conv kernel: 0 = automatic (128x128 tiles for small problems, the default
  * 256x256 schedule for large ones; 64x128 tiles where 128x128 would leave CUs idle), 1 = force 128x128 (4 waves, 2
  * workgroups per CU), 2 = force 64x128 (same kernel, half the rows, 3 workgroups per CU), 7 = force the 8-wave ping-pong
- * 256x256 schedule (two waves per SIMD), 10 = force the one-wave-per-SIMD 256x256 schedule (4 waves, 128x128 per wave);
+ * 256x256 schedule (two waves per SIMD);
  * 400 + b sets the band height b (in m-tiles) of the 256x256 tile order; 500 / 501 switch the automatic use of the 64x128
  * tiling off / on. */
 int mk_gemm_set_tile(int mode);
 
-/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for large grids, 4 for small), 1 = 32 queries/wave,
- * 2 = 64 queries/wave, 3 = software-pipelined (QK^T of tile t+1 overlaps the softmax of tile t), 4 = VALU-lean (max
- * folded into the MFMA accumulator init, row sums on the matrix pipe), 5 = VALU-lean with 8 waves.  Process-wide; for
- * benchmarks and tests. */
+/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (the large-grid kernel for >= 512 workgroups of 256 queries, 4 for
+ * small grids), 1 = 32 queries/wave, 2 = 64 queries/wave (both two waves per SIMD), 4 = VALU-lean (max folded into the
+ * MFMA accumulator init, row sums on the matrix pipe), 7 = one wave per SIMD (64 queries per wave, K / V^T fragments and
+ * the output accumulators in the accumulator register file, hand-placed MFMA / softmax interleave; problems with fewer
+ * than 4 KV tiles run variant 2).  Process-wide; for benchmarks and tests. */
 int mk_attn_set_mode(int mode);
 
 #ifdef __cplusplus

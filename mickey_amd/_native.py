@@ -41,7 +41,7 @@ SIGNATURES = {
     "mk_linattn_kv": ("i", "pppiiiip"),
     "mk_linattn_apply": ("i", "pppiiiiiip"),
     "mk_head_tails": ("i", "pppppppppppiiiiiiiififp"),
-    "mk_dual_softmax_work_floats": ("l", "iii"),
+    "mk_dual_softmax_work_floats": ("l", "iiii"),
     "mk_dual_softmax": ("i", "ppppfifppppiiiip"),
     "mk_sinkhorn_work_floats": ("l", "iii"),
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),

@@ -66,15 +66,24 @@ def _parse_resource_remarks(out):
     return kernels, "\n".join(rest)
 
 
-def resource_usage(ensure=True):
-    """{source file: [per-kernel register / scratch / spill figures]} of the current build; with ensure, sources that have no
-    entry yet (objects built before this report existed) are recompiled."""
-    usage = _load_usage()
-    srcs = [os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))]
-    if ensure and any(s not in usage for s in srcs):
-        build(force=True, verbose=False)
-        usage = _load_usage()
-    return usage
+def resource_usage():
+    """{source file: [per-kernel register / scratch / spill figures]} as recorded by the last build() of each source (a pure
+    query: it never compiles; sources without an entry -- objects built before this report existed -- are simply absent,
+    `python -m mickey_amd.build --force` refreshes everything).  Entries of sources that no longer exist are dropped."""
+    srcs = {os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))}
+    return {k: v for k, v in _load_usage().items() if k in srcs}
+
+
+def source_hash():
+    """Identity of the kernel sources (csrc/*.hip, csrc/*.hpp, include/*.h): profiles/ files record it so that bench.py can
+    tell whether a committed counter file was collected from the kernels it is running (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def hipcc():
@@ -123,7 +132,8 @@ def build(force=False, save_temps=False, verbose=True):
         return s, r.returncode, r.stdout
 
     failed = False
-    usage = _load_usage()
+    have = {os.path.basename(x) for x in srcs}
+    usage = {k: v for k, v in _load_usage().items() if k in have}   # entries of deleted / renamed sources go
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for s, rc, out in ex.map(run, jobs):
             if verbose:

@@ -21,10 +21,6 @@
 // XCD (private L2) walk a contiguous range of tiles.
 #include "mk_gemm_common.hpp"
 
-#ifndef MK_GEMM_DEFAULT_BIG
-#define MK_GEMM_DEFAULT_BIG 7   // schedule of large problems under mk_gemm_set_tile(0): 7 = 8-wave ping-pong, 10 = one wave per SIMD
-#endif
-
 namespace mk {
 namespace gemm {
 namespace {
@@ -132,7 +128,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
 int g_num_cus = 0;
 int g_band_m = 8;      // m-tiles per band of the 256x256 tile order (dev: mk_gemm_set_tile 400 + b)
 int g_half_rows = 1;   // automatic choice may use the 64x128 tiling for under-filled launches (dev: 500 off / 501 on)
-int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong, 10 force one-wave-per-SIMD
+int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong
 
 template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
@@ -152,10 +148,8 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
     return launch_f32(p, groups, AMODE, st);
   }
   int sched = g_schedule;
-  if (sched == 0) sched = (big && k_ok) ? MK_GEMM_DEFAULT_BIG : 1;
+  if (sched == 0) sched = (big && k_ok) ? 7 : 1;
   if (!k_ok) sched = 1;
-  if (sched == 10 && ln_fold) sched = 7;   // the one-wave-per-SIMD A/B partner has no folded-LayerNorm epilogue
-  if (sched == 10) return launch_w4(p, groups, dtype, AMODE, st, g_band_m);
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
   // 128x128 tiles fill a 256-CU part (2 workgroups per CU) from 512 tiles on; below that 64-row tiles double the count
   const long long small_tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * groups;
@@ -204,8 +198,8 @@ int mk_gemm_set_tile(int mode) {
     g_half_rows = mode - 500;
     return MK_OK;
   }
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7 || mode == 10,
-               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong, 10 one wave per SIMD)", mode);
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7,
+               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong)", mode);
   g_schedule = mode;
   return MK_OK;
 }

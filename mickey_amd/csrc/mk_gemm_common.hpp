@@ -1,5 +1,5 @@
 // mickey_amd -- shared pieces of the 16-bit-operand MFMA GEMMs (mk_gemm.hip: dispatch + 128x128 kernel,
-// mk_gemm_pp64.hip: 8-wave ping-pong, mk_gemm_w4.hip: one wave per SIMD): parameters, LDS-DMA stager, epilogues.
+// mk_gemm_pp64.hip: 8-wave ping-pong): parameters, LDS-DMA stager, epilogues.
 #pragma once
 #include "mk_common.hpp"
 
@@ -809,7 +809,6 @@ int num_cus();
 // schedule launchers (one translation unit each); amode = A_DENSE | A_CONV3, dtype = MK_BF16 | MK_F16
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
 int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)
-int launch_w4(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
 
 }  // namespace gemm
 }  // namespace mk

@@ -478,10 +478,12 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 
 extern "C" {
 
-long long mk_dual_softmax_work_floats(int B, int n0, int n1) {
+long long mk_dual_softmax_work_floats(int B, int n0, int n1, int own_copy) {
   const long long nmax = n0 > n1 ? n0 : n1, nrb = (n0 + RT - 1) / RT;
-  // row partials + column partials + final log2-sum-exp vectors + the stored correlation (unused when `scores` is given)
-  return (long long)B * NCHUNK * n0 * 2 + (long long)B * nrb * n1 * 2 + (long long)B * 2 * nmax + 4 + (long long)B * n0 * n1;
+  // row partials + column partials + final log2-sum-exp vectors (+ the stored correlation: only a call that asks for
+  // neither `scores` nor `final_scores` keeps it in `work`; at B = 32, n = 1938 that term alone is 480 MB)
+  return (long long)B * NCHUNK * n0 * 2 + (long long)B * nrb * n1 * 2 + (long long)B * 2 * nmax + 4 +
+         (own_copy ? (long long)B * n0 * n1 : 0);
 }
 
 int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,

@@ -86,12 +86,29 @@ class PoseGatherer:
     def wait(self, handle):
         done, out = handle
         if done is not None:
-            torch.cuda.current_stream(out[0].device).wait_event(done)
+            main = torch.cuda.current_stream(out[0].device)
+            main.wait_event(done)
+            for o in out:   # allocated on the side stream, used on the main one from here on: tell the caching allocator, or
+                o.record_stream(main)   # the next submit() may reuse the block while queued main-stream work still reads it
         return out
 
 
 def _empty_poses(device):
     return (torch.zeros((0, 3, 3), device=device), torch.zeros((0, 1, 3), device=device), torch.zeros((0, 1), device=device))
+
+
+def forward_local(model, local, sizes, gatherer=None):
+    """The second half of forward_sharded for a caller that already holds only ITS slice of the global batch (`local`, with
+    `pair_base` set; `sizes` = every rank's slice length): forward (skipped for an empty slice), then the all-gather."""
+    if local["image0"].shape[0] > 0:
+        R, t = model(local)
+        conf = local["inliers"]
+    else:
+        R, t, conf = _empty_poses(local["image0"].device)
+        local["R"], local["t"], local["inliers"] = R, t, conf
+    if gatherer is not None:
+        return gatherer.wait(gatherer.submit(R, t, conf, sizes))
+    return gather_poses(R, t, conf, sizes)
 
 
 def forward_sharded(model, data, return_local=False, gatherer=None):

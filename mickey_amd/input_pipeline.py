@@ -99,7 +99,13 @@ class PairFeeder:
     All frames must share one stored size (Map-free: 540 x 720); `resize` = (W, H) the model runs at.
     """
 
-    def __init__(self, records, batch_size, resize, device="cuda:0", workers=None, slots=3):
+    def __init__(self, records, batch_size, resize, device="cuda:0", workers=None, slots=3, batches=None):
+        """batches: explicit list of record lists (each at most batch_size long, empty ones allowed) instead of cutting
+        `records` into runs of batch_size -- a rank of a sharded evaluation passes its slice of every global batch, so it
+        decodes, pins and uploads only the frames it will process; an empty slice yields a dict with 0-row tensors."""
+        self._batches = None if batches is None else [list(b) for b in batches]
+        if self._batches is not None:
+            records = [r for b in self._batches for r in b]
         self.records, self.B, self.resize = list(records), int(batch_size), (int(resize[0]), int(resize[1]))
         self.device = torch.device(device)
         self.workers = workers or min(32, max(2, (os.cpu_count() or 4) // 2))
@@ -107,7 +113,11 @@ class PairFeeder:
         self._ring = None
 
     def __len__(self):
-        return (len(self.records) + self.B - 1) // self.B
+        return len(self._batches) if self._batches is not None else (len(self.records) + self.B - 1) // self.B
+
+    def _empty(self, H, W):
+        z = lambda *s: torch.zeros(s, device=self.device)  # noqa: E731
+        return {"image0": z(0, 3, H, W), "image1": z(0, 3, H, W), "K_color0": z(0, 3, 3), "K_color1": z(0, 3, 3)}
 
     @staticmethod
     def _decode_into(dst, src):
@@ -118,17 +128,20 @@ class PairFeeder:
 
     def __iter__(self):
         recs = self.records
+        W, H = self.resize
         if not recs:
+            for _ in (self._batches or []):   # a rank that owns nothing still steps through every global batch
+                yield self._empty(H, W)
             return
         first = recs[0]["image0"]
         probe = first if isinstance(first, np.ndarray) else decode_rgb(first)
         Hs, Ws = probe.shape[:2]
-        W, H = self.resize
-        if self._ring is None or (self._ring.Hs, self._ring.Ws) != (Hs, Ws):
-            self._ring = FrameRing(self.B, Hs, Ws, self.device, self.slots)
+        if self._ring is None or (self._ring.Hs, self._ring.Ws) != (Hs, Ws) or self._batches is not None:
+            ring_b = max(len(b) for b in self._batches) if self._batches is not None else self.B
+            self._ring = FrameRing(ring_b, Hs, Ws, self.device, self.slots)
         ring = self._ring
         sx, sy = W / Ws, H / Hs
-        batches = [recs[i:i + self.B] for i in range(0, len(recs), self.B)]
+        batches = self._batches if self._batches is not None else [recs[i:i + self.B] for i in range(0, len(recs), self.B)]
         with concurrent.futures.ThreadPoolExecutor(self.workers) as pool:
             def stage(bi):
                 slot = bi % self.slots
@@ -152,6 +165,9 @@ class PairFeeder:
                 if nxt < len(batches):
                     pending[nxt] = stage(nxt)   # decode the batch after next while this one is copied / computed
                 n = len(batch)
+                if n == 0:
+                    yield self._empty(H, W)
+                    continue
                 im0, im1 = ring.to_model_input(slot, H, W, n)
                 K0 = torch.stack([correct_intrinsic_scale(torch.as_tensor(r["K_color0"], dtype=torch.float32), sx, sy) for r in batch])
                 K1 = torch.stack([correct_intrinsic_scale(torch.as_tensor(r["K_color1"], dtype=torch.float32), sx, sy) for r in batch])

@@ -117,25 +117,37 @@ def missing_inputs(dataset_path, split, checkpoint):
     return why
 
 
-def predict_to_zip(model, records, batch_size, resize, output_zip, sharded=False, device="cuda:0"):
-    """records -> poses -> zip (reference submission.py:32-68).  With `sharded`, every rank runs this on the same records;
-    each forward handles its slice of the batch and one all-gather returns all poses; rank 0 writes the file."""
+def predict_to_zip(model, records, batch_size, resize, output_zip, sharded=False, device="cuda:0", rank=None, world=None):
+    """records -> poses -> zip (reference submission.py:32-68).  With `sharded`, every rank runs this on the same record
+    LIST but feeds (decodes, pins, uploads, preprocesses) only its contiguous slice of every global batch; one all-gather
+    per batch returns all poses and rank 0 writes the file.  The Philox streams are keyed by the position in the global
+    batch (`pair_base`), so the poses equal those of an unsharded run."""
     import torch
+    from . import distributed as D
     from . import submission_io as sio
     from .input_pipeline import PairFeeder
     from collections import defaultdict
     results = defaultdict(list)
-    feeder = PairFeeder(records, batch_size, resize, device=device)
-    for data in feeder:
+    if sharded:
+        import torch.distributed as dist
+        rank = dist.get_rank() if rank is None else rank
+        world = dist.get_world_size() if world is None else world
+    else:
+        rank, world = 0, 1
+    gbatches = [records[i:i + batch_size] for i in range(0, len(records), batch_size)]
+    spans = [[D.shard_range(len(b), r, world) for r in range(world)] for b in gbatches]
+    feeder = PairFeeder(None, batch_size, resize, device=device,
+                        batches=[b[sp[rank][0]:sp[rank][1]] for b, sp in zip(gbatches, spans)])
+    for data, gb, sp in zip(feeder, gbatches, spans):
         with torch.no_grad():
             if sharded:
-                from . import distributed as D
-                R, t, inl = D.forward_sharded(model, data)
+                data["pair_base"] = sp[rank][0]
+                R, t, inl = D.forward_local(model, data, [hi - lo for lo, hi in sp])
             else:
                 R, t = model(data)
                 inl = data["inliers"]
-        sio.append_batch(results, data["scene_id"], data["pair_names"][1], R.detach().cpu().numpy(), t.detach().cpu().numpy(),
-                         inl.detach().cpu().numpy())
+        sio.append_batch(results, [r["scene_id"] for r in gb], [r["pair_names"][1] for r in gb], R.detach().cpu().numpy(),
+                         t.detach().cpu().numpy(), inl.detach().cpu().numpy())
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
         sio.save_submission(results, output_zip)

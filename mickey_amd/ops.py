@@ -207,7 +207,8 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
     scores = mk(want_scores)
     kp = mk(want_kp and scr0 is not None)
     fin = mk(want_final and scr0 is not None)
-    work = torch.empty((query("mk_dual_softmax_work_floats", B, n0, n1),), device=dev, dtype=torch.float32)
+    work = torch.empty((query("mk_dual_softmax_work_floats", B, n0, n1, int(scores is None and fin is None)),), device=dev,
+                       dtype=torch.float32)
     call("mk_dual_softmax", ptr(dsc0), ptr(dsc1), ptr(scr0), ptr(scr1), 1.0 / float(temperature), int(dustbin is not None),
          float(dustbin) if dustbin is not None else 0.0, ptr(scores), ptr(kp), ptr(fin), ptr(work), B, C, n0, n1, stream())
     return scores, kp, fin

@@ -147,9 +147,19 @@ class MetricPoseLoss(torch.nn.Module):
             self.topK = C["TOPK_INIT"]
         elif C["TRAIN_WITH_TOPK"]:
             self.topK = C["TOPK"]
-        # Philox streams of the two samplers: (seed, 2 * call) and (seed, 2 * call + 1)
+        # Philox streams of the two samplers: (seed, 2 * call) and (seed, 2 * call + 1), keyed further by the pair index.
+        # Under DDP every rank constructs this class with the same seed and advances _calls in lockstep, so without a
+        # per-rank offset all ranks would draw IDENTICAL noise for their (different) pairs -- unbiased, but the REINFORCE
+        # variance reduction of data parallelism would be lost.  When batch['pair_base'] is absent the pair index is
+        # therefore offset by rank * 2^20 (read lazily: the process group usually does not exist yet here); a caller that
+        # shards one global batch itself passes pair_base and gets sharding-invariant draws instead.
         self.seed = int(seed)
         self._calls = 0
+
+    @staticmethod
+    def _default_pair_base():
+        import torch.distributed as dist
+        return (dist.get_rank() << 20) if dist.is_available() and dist.is_initialized() else 0
 
     def read_pose_parameters(self, batch):
         """reference loss_class.py:71-78."""
@@ -189,7 +199,7 @@ class MetricPoseLoss(torch.nn.Module):
             # which the reference skips the loop (:118-124) or lands in its except branch (:263-270)
             invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
             idx_outer, cnt = ops.exprace_topk(rowp, it_m, S, seed=self.seed, offset=2 * call, invalid=invalid,
-                                              pair_base=int(batch.get("pair_base", 0)))
+                                              pair_base=int(batch.get("pair_base", self._default_pair_base())))
             if int(invalid.item()) != 0 or int((cnt < S).any().item()) != 0:
                 print("Invalid matching matrix! Skip RANSAC loop.")
                 return bail()
@@ -206,7 +216,7 @@ class MetricPoseLoss(torch.nn.Module):
         # hypotheses + refinement, no autograd (the reference wraps the same steps in torch.no_grad, :152-184)
         mask, idx_in, rounds = ops.train_ransac_masks(
             X.detach(), Y.detach(), weights, it_r, float(self.inlier_ref_th), self.num_ref_steps, nc, idx_in=idx_inner,
-            seed=self.seed, offset=2 * call + 1, set_base=int(batch.get("pair_base", 0)) * it_m)
+            seed=self.seed, offset=2 * call + 1, set_base=int(batch.get("pair_base", self._default_pair_base())) * it_m)
         X_v = X.unsqueeze(1).expand(Ro, it_r, S, 3).reshape(Ri, S, 3)
         Y_v = Y.unsqueeze(1).expand(Ro, it_r, S, 3).reshape(Ri, S, 3)
         R, t, H = weighted_procrustes_masked(X_v, Y_v, mask)

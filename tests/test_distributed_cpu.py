@@ -94,3 +94,59 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+# ---- sharded evaluation: every rank feeds only ITS slice of each global batch (mapfree_eval.predict_to_zip) -------------
+class _FakeFeeder:
+    """Stands in for input_pipeline.PairFeeder (which needs a GPU): records carry a scalar `val`, the 'image' is that value;
+    the records a rank was asked to feed are logged."""
+    fed = []
+
+    def __init__(self, records, batch_size, resize, device="cpu", batches=None, **kw):
+        assert records is None and batches is not None and all(len(b) <= batch_size for b in batches)
+        self.batches = batches
+
+    def __iter__(self):
+        for b in self.batches:
+            _FakeFeeder.fed.extend(r["val"] for r in b)
+            v = torch.tensor([r["val"] for r in b], dtype=torch.float32)
+            yield {"image0": v.view(-1, 1, 1, 1).expand(-1, 3, 2, 2).contiguous(), "image1": torch.zeros(len(b), 3, 2, 2)}
+
+
+def _eval_worker(rank, world, port, n, bs, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mickey_amd import input_pipeline, mapfree_eval as ME
+    input_pipeline.PairFeeder = _FakeFeeder
+    recs = [{"val": float(i + 1), "scene_id": "s%d" % (i % 2), "pair_names": ("a.jpg", "q%03d.jpg" % i)} for i in range(n)]
+    seen = []
+
+    class M(_FakeModel):
+        def __call__(self, data):
+            seen.append(int(data.get("pair_base", -1)))
+            return super().__call__(data)
+    res = ME.predict_to_zip(M(), recs, bs, (2, 2), os.path.join(tmp, "r%d.zip" % rank), sharded=True, device="cpu")
+    lines = sorted(str(p) for plist in res.values() for p in plist)
+    q.put((rank, list(_FakeFeeder.fed), seen, lines, os.path.exists(os.path.join(tmp, "r%d.zip" % rank))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_feeds_only_the_local_slice(tmp_path):
+    """7 records, global batches of 4 (4 + 3), 2 ranks: rank 0 feeds records {1,2,5,6}, rank 1 {3,4,7}; both end up with the
+    poses of all 7 pairs in global order; pair_base = the slice's offset inside its global batch; only rank 0 writes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, 7, 4, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, fed0, seen0, lines0, wrote0), (r1, fed1, seen1, lines1, wrote1) = res
+    assert fed0 == [1.0, 2.0, 5.0, 6.0] and fed1 == [3.0, 4.0, 7.0]
+    assert seen0 == [0, 0] and seen1 == [2, 2]
+    assert lines0 == lines1 and len(lines0) == 7
+    assert wrote0 and not wrote1

@@ -46,7 +46,8 @@ def test_abi_rejects_bad_arguments_without_a_device(nv):
     assert b"gemm" in lib.mk_last_error()
     assert lib.mk_layernorm(None, 0, None, None, 1e-6, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
     # row partials (4 column chunks) + column partials (1 row block) + final LSE vectors + pad + the stored correlation
-    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4 + 2 * 10 * 12
+    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 1) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4 + 2 * 10 * 12
+    assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 0) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4
     assert nv.query("mk_exprace_topk_work_bytes", 1, 20, 2048) > 20 * 8192 * 8
     with pytest.raises(nv.MickeyHipError):
         nv.call("mk_flash_attn_fwd", None, None, None, None, 0, 0, 0, 0, 0, 0, None)
@@ -147,20 +148,23 @@ def test_no_product_kernel_spills_registers():
     """Per-kernel register report of the build (hipcc -Rpass-analysis=kernel-resource-usage -> build/resource_usage.json).
     All epilogues of a GEMM kernel share ONE register allocation: a variant over 256 VGPRs makes hipcc spill the
     accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward).
-    Development-only schedules (the one-wave-per-SIMD GEMM, the pinned-interleave attention) are exempt."""
+    No kernel of the library is exempt.  The report is written by build(); a checkout whose objects were built elsewhere
+    (no json) skips."""
+    import glob
+    import os
     from mickey_amd import build as B
     usage = B.resource_usage()
-    dev_only = ("gemm_w4_kernel", "attn_fwd_lp_kernel")
+    srcs = [os.path.basename(p) for p in glob.glob(os.path.join(B.CSRC, "*.hip"))]
+    if any(s not in usage for s in srcs):
+        pytest.skip("no register report for %s (run python -m mickey_amd.build --force)" % [s for s in srcs if s not in usage])
     seen = 0
     for src, kernels in usage.items():
         for k in kernels:
-            if any(d in k["name"] for d in dev_only):
-                continue
             seen += 1
             # (SGPR spills go to spare VGPR lanes, not to memory: several kernels have a few, they are not asserted on)
             assert k.get("vgpr_spill", 0) == 0, (src, k)
             assert k.get("scratch", 0) <= 32, (src, k)   # 32 B: the V^T element-store path of the qkv epilogue
-    assert seen > 50 and any("gemm_pp64_kernel" in k["name"] for k in usage.get("mk_gemm_pp64.hip", []))
+    assert seen > 40 and any("gemm_pp64_kernel" in k["name"] for k in usage.get("mk_gemm_pp64.hip", []))
 
 
 def test_fold_layernorm_is_an_identity():

@@ -34,7 +34,7 @@ def _auto_tile():
         ops.attn_set_mode(0)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])
 def test_gemm_bias_act(dtype, M, N, K, tile):
@@ -60,7 +60,7 @@ def test_gemm_bias_act(dtype, M, N, K, tile):
     assert torch.equal(out.cpu(), w.float()[:, :64].t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 4096), (700, 384, 256)])
 def test_gemm_ls_residual(M, N, K, tile):
     from mickey_amd import ops
@@ -76,7 +76,7 @@ def test_gemm_ls_residual(M, N, K, tile):
     assert rel(xd, ref) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 def test_gemm_qkv_layout(tile):
     from mickey_amd import ops
     dev = _dev()
@@ -101,7 +101,7 @@ def test_gemm_qkv_layout(tile):
     assert float(q[:, :, ntok:].abs().sum()) == 0.0  # pad rows untouched
 
 
-@pytest.mark.parametrize("tile", [0, 7, 10])
+@pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("nimg,H,W,D", [(2, 75, 101, 256), (3, 300, 290, 384)])   # 5 x 7 and 21 x 20 patches
 def test_patch_embed_and_cls(nimg, H, W, D, tile):
     from mickey_amd import ops
@@ -139,7 +139,7 @@ def _split(x, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 256), (700, 384, 128), (257, 128, 64)])
 def test_ln_fold_producer_residual(M, N, K, tile, dtype):
     """mk_gemm_ls_residual_ln on the split residual stream (x = hi + lo): the new fp32 rows are what mk_gemm_ls_residual
@@ -236,7 +236,7 @@ def _ln_fold_inputs(M, D, N, dtype, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("M,D,N,act", [(3878, 1024, 1024, 2), (700, 384, 512, 0), (130, 128, 256, 2)])
 def test_ln_fold_consumer_gemm(M, D, N, act, tile, dtype):
     """mk_gemm_ln == act(LayerNorm(x) @ W^T + b) with the normalisation applied in the epilogue: exact (fp32 accumulation)
@@ -300,11 +300,11 @@ def test_layernorm(D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("mode", [0, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4, 7])
 @pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])
 def test_flash_attention(dtype, ntok, nimg, heads, mode):
-    """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the 64-queries-per-wave instantiation in auto
-    mode; mode 3 is the software-pipelined kernel."""
+    """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the large-grid kernel in auto mode; modes: 1 / 2 = 32 / 64
+    queries per wave (two waves per SIMD), 4 = VALU-lean, 7 = one wave per SIMD (falls back to mode 2 below 4 KV tiles)."""
     from mickey_amd import ops
     dev = _dev()
     ops.attn_set_mode(mode)
@@ -329,7 +329,7 @@ def test_flash_attention(dtype, ntok, nimg, heads, mode):
     assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
 
 
-@pytest.mark.parametrize("tile", [1, 2, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("with_sc,with_res", [(False, False), (True, False), (False, True)])
 def test_conv3x3(with_sc, with_res, tile):
     from mickey_amd import ops

@@ -156,6 +156,42 @@ def test_full_size_pair_vs_oracle(cfg, dtype):
     assert bool((v_mine[:-1] >= v_mine[1:]).all())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_full_forward_vs_oracle_vit_small(cfg, dtype):
+    """The encoder size BASELINE.json's north_star names: DINOv2 ViT-S/14 (D = 384, 12 blocks, 6 heads; reference
+    DINO_modules/dinov2.py:306-316) in front of the same heads / matcher, one 720x540 pair against the CPU oracle (heads=6).
+    D = 384 takes the generic folded-LayerNorm path (6 statistics slots per row) and K = 384 GEMMs (6 K stages)."""
+    import copy
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    from mickey_amd.model import MickeyRelativePose
+    from oracle import mickey_oracle as O
+    c = copy.deepcopy(cfg)
+    c["AMD"]["ENCODER_DTYPE"] = dtype
+    c["AMD"]["VIT"] = "vit_small"
+    c["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = 384
+    sd = syn.mickey_state_dict(c, seed=0, arch="vit_small")
+    model = MickeyRelativePose(c)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    batch = syn.synthetic_batch(B=1, H=720, W=540, seed=1234)
+    data = {k: v.to(dev) for k, v in batch.items()}
+    R, t = model(data)
+    assert model.device_weights().D == 384 and model.device_weights().heads == 6 and len(model.device_weights().blocks) == 12
+    odata = {k: v.clone() for k, v in batch.items()}
+    with torch.no_grad():
+        odata.update(O.compute_correspondences(sd, c, odata, heads=6))
+    tol = TOL[model.lp_dtype]
+    errs = {k: rel(data[k], odata[k]) for k in KEYS}
+    print("vit_small 720x540", dtype, {k: "%.2e" % v for k, v in errs.items()})
+    for k in KEYS:
+        base = k.rstrip("01").replace("depth_kp", "depth")
+        assert errs[k] < (1.0 if dtype == "fp32" else 1.5) * tol[base], (k, errs[k])
+    assert data["scores"].shape == (1, 1938, 1938) and torch.isfinite(R).all() and torch.isfinite(t).all()
+    det = torch.linalg.det(R.double().cpu())
+    assert ((det - 1).abs() < 1e-4).all() or float(R.abs().sum()) == 0.0
+
+
 def test_forward_determinism_lean_and_shapes(cfg):
     dev = _dev()
     from mickey_amd import synthetic as syn

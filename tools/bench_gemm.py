@@ -1,5 +1,5 @@
 """GEMM schedule A/B on the encoder shapes (dev tool).  python tools/bench_gemm.py [modes...]
-modes: mk_gemm_set_tile values (7 = 8-wave ping-pong, 10 = one wave per SIMD); -1 = torch.matmul (hipBLASLt), bare.
+modes: mk_gemm_set_tile values (7 = 8-wave ping-pong); -1 = torch.matmul (hipBLASLt), bare.
 Each shape is timed bare (bf16 store) and with its in-forward epilogue (qkv split / LayerScale+residual / bias+GELU).
 Repetitions are interleaved over the schedules and the median is reported (clock / power drift on one box is a few %)."""
 import math
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mickey_amd import ops  # noqa: E402
 from tools.bench_kernels import timeit  # noqa: E402
 
-modes = [int(t) for t in sys.argv[1:]] or [7, 10, -1]
+modes = [int(t) for t in sys.argv[1:]] or [7, -1]
 dev = torch.device("cuda:0")
 nimg, ntok, pad, heads = 64, 1939, 1984, 16
 M = nimg * ntok
