@@ -37,8 +37,8 @@ def role(name):
     """kernel name (mangled or demangled) -> role key"""
     if "gemm_pp64_kernel" in name:
         m = re.search(r"gemm_pp64_kernelI\w+?Li(\d)ELi(\d)E", name) or re.search(r"gemm_pp64_kernel<[^,]+,\s*(\d)[^,]*,\s*(\d)", name)
-        if not m:
-            return "gemm_pp64_other"
+        if not m:   # rocprofv3 prints some instantiations half-demangled ("gemm_pp64_kernel<bool _Accum, int, E, 0>"): the conv ones
+            return "conv_gemm(+unparsed pp64 names)"
         amode, kind = int(m.group(1)), int(m.group(2))
         if amode == 1:
             return "conv_gemm"
