@@ -111,11 +111,11 @@ class StageProfiler:
         timed("gemm_patch_embed", "encoder_gemm", mnk,
               lambda a, w, bias, pos, x, nimg, npatch: opnd(a, w) + a.shape[0] * w.shape[0] * 4 + pos.numel() * 4)
         # LayerNorm folded in
-        timed("gemm_ln", "encoder_gemm", mnk, lambda a, w, bias, colsum, stats, eps, act=0, out=None:
+        timed("gemm_ln", "encoder_gemm", mnk, lambda a, w, bias, colsum, stats, eps, act=0, out=None, **k:
               opnd(a, w) + a.shape[0] * w.shape[0] * esz(a) + stat(a.shape[0], w.shape[1]))
         timed("gemm_qkv_ln", "encoder_gemm", mnk, lambda a, w, bias, colsum, stats, *r, **k:
               opnd(a, w) + a.shape[0] * w.shape[0] * esz(a) + stat(a.shape[0], w.shape[1]))
-        timed("gemm_ls_residual_ln", "encoder_gemm", mnk, lambda a, w, bias, gamma, xh, xl, stats, x_out=None:
+        timed("gemm_ls_residual_ln", "encoder_gemm", mnk, lambda a, w, bias, gamma, xh, xl, stats, x_out=None, **k:
               opnd(a, w) + 2 * esz(xh) * xh.numel() + (4 * xh.numel() if x_out is not None else
                                                       2 * esz(xh) * xh.numel() + stat(a.shape[0], w.shape[0])))
         timed("gemm_patch_embed_ln", "encoder_gemm", mnk, lambda a, w, bias, pos, xh, xl, stats, nimg, npatch:

@@ -109,20 +109,25 @@ int mk_cls_token(const float* cls, const float* pos, float* x, int nimg, int nto
  *   x_f32_out (mk_gemm_ls_residual_ln): if not NULL the updated rows go there as fp32 [M, ldx] and hi / lo / stats are
  *           left alone -- the last block, whose output feeds the final norm.
  *   colsum fp32 [N]: sum_k W'[n][k] over the 16-bit-ROUNDED folded weights (so that the mean term cancels exactly what
- *           the MFMA accumulates);  bias = b + W . b_ln (fp32, folded on the host);  eps as nn.LayerNorm (1e-6). */
+ *           the MFMA accumulates);  bias = b + W . b_ln (fp32, folded on the host);  eps as nn.LayerNorm (1e-6).
+ *   Row centring (shift_out / shift_in, fp32 [M], each may be NULL = off): LayerNorm is blind to a constant added to all
+ *           channels of a row and nothing but LayerNorm reads the residual stream, so the stream may carry a per-row offset.
+ *           A consumer publishes every row's current mean in shift_out; the next producer subtracts shift_in while it adds the
+ *           branch output.  Rows then stay centred to within one residual update and the 16-bit hi plane rounds x - mean
+ *           instead of x: the folded form's operand rounding becomes that of a LayerNorm OUTPUT at any common-mode level. */
 int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, void* xh,
-                           void* xl, int ldxs, float* stats, float* x_f32_out, int ldx, int M, int N, int K, int dtype,
-                           mk_stream_t stream);
+                           void* xl, int ldxs, float* stats, const float* shift_in, float* x_f32_out, int ldx, int M, int N,
+                           int K, int dtype, mk_stream_t stream);
 int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* pos, void* xh,
                            void* xl, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream);
 int mk_cls_token_ln(const float* cls, const float* pos, void* xh, void* xl, float* stats, int nimg, int ntok, int D, int dtype,
                     mk_stream_t stream);
 /* consumers: mk_gemm (bias, optional GELU, 16-bit output) and mk_gemm_qkv with A = the hi plane [M, K] (lda == K) */
 int mk_gemm_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
-               float eps, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream);
+               float eps, float* shift_out, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream);
 int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
-                   float eps, void* q, void* k, void* vt, int nimg, int ntok, int ntok_pad, int heads, float qscale, int dtype,
-                   mk_stream_t stream);
+                   float eps, float* shift_out, void* q, void* k, void* vt, int nimg, int ntok, int ntok_pad, int heads,
+                   float qscale, int dtype, mk_stream_t stream);
 
 /* LayerNorm over the last dim (dinov2.py:87,230; block.py:84,87; transformer_utils.py:37-38).
  * x fp32 [*, ldx]; output row r reads input row (r / (rows_per_img - skip)) * rows_per_img + skip +

@@ -26,11 +26,11 @@ SIGNATURES = {
     "mk_gemm_ls_residual": ("i", "pipipppiiiiip"),
     "mk_gemm_qkv": ("i", "pipippppiiiifip"),
     "mk_gemm_patch_embed": ("i", "pipipppiiiiip"),
-    "mk_gemm_ls_residual_ln": ("i", "pipippppippiiiiip"),
+    "mk_gemm_ls_residual_ln": ("i", "pipippppipppiiiiip"),
     "mk_gemm_patch_embed_ln": ("i", "pipipppppiiiiip"),
     "mk_cls_token_ln": ("i", "pppppiiiip"),
-    "mk_gemm_ln": ("i", "pipipppfpiiiiiip"),
-    "mk_gemm_qkv_ln": ("i", "pipipppfpppiiiifip"),
+    "mk_gemm_ln": ("i", "pipipppfppiiiiiip"),
+    "mk_gemm_qkv_ln": ("i", "pipipppfppppiiiifip"),
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
     "mk_layernorm": ("i", "pippfpiipiiiiiiip"),

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 // Per tile and wave: 20 MFMAs and ~70 VALU instructions (16 max3, 32 exp, 16 cvt).
 constexpr float ATT_REBASE_THR = 8.0f;
 
-template <typename T>
+// MSUM: row sums on the matrix pipe (ones . P^T); false: as 32 fp32 adds per tile on the VALU.  The part runs this kernel at
+// its POWER limit (profiles/r03_pmc_clock.json: every attention variant ends at the same wall time, the ones that need fewer
+// cycles at a lower clock), where what counts is energy per tile: the 4 row-sum MFMAs are a fifth of the matrix work.
+template <typename T, bool MSUM>
 __global__ __launch_bounds__(256, 3) void attn_fwd_lean_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                const T* __restrict__ vt, T* __restrict__ out, int ldo,
                                                                int heads, int ntok, int ntok_pad) {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_lean_kernel(const T* __restri
     lsum[i] = 0.f;
     negm[i] = 0.f;          // m_run = 0 to start with; the first tile re-bases (scores are bounded by |q||k|)
   }
-  float m_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;   // l_run: this lane's share of the row sum (VALU form; lanes j and j + 32 are added at the end)
   bool first = true;
 
   const int nkt = (ntok + 63) >> 6;
@@ -327,22 +330,32 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_lean_kernel(const T* __restri
       for (int i = 0; i < 16; ++i) {
         o[0][i] *= alpha;
         o[1][i] *= alpha;
-        lsum[i] *= alpha;
+        if (MSUM) lsum[i] *= alpha;
         s[0][i] -= shift;
         s[1][i] -= shift;
       }
+      l_run *= alpha;
       m_run += shift;
 #pragma unroll
       for (int i = 0; i < 16; ++i) negm[i] = -m_run;
       first = false;
     }
     V8 pf[4];
+    float rs4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 32-deep dependent add chain
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)__builtin_amdgcn_exp2f(s[s4 >> 1][(s4 & 1) * 8 + e]);
+      for (int e = 0; e < 8; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[s4 >> 1][(s4 & 1) * 8 + e]);
+        pf[s4][e] = (T)pv;
+        if (!MSUM) rs4[e & 3] += pv;
+      }
+    if (MSUM) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) lsum = Lp<T>::mma32(ones, pf[s4], lsum);   // row sums on the matrix pipe
+      for (int s4 = 0; s4 < 4; ++s4) lsum = Lp<T>::mma32(ones, pf[s4], lsum);   // row sums on the matrix pipe
+    } else {
+      l_run += (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+    }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int row = dt * 32 + j;
@@ -352,6 +365,203 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_lean_kernel(const T* __restri
         o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
       }
     }
+  }
+
+  // MSUM: every accumulator row of ones.P^T holds the full row sum of this lane's query
+  const float inv = 1.0f / (MSUM ? lsum[0] : l_run + __shfl_xor(l_run, 32, 64));
+  const int qi = q0 + j;
+  if (qi < ntok) {
+    T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        V4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][r4 * 4 + e] * inv);
+        *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong kernel (mode 8): 8 waves = two wave-rows of 4, 32 queries per wave, two waves per SIMD -- one of each row.
+// Why: with two free-running waves per SIMD the per-tile barrier starts both of them in the SAME phase (both issue their
+// QK^T MFMAs, then both run their softmax on the VALU, then both their P.V MFMAs), so the matrix pipe and the VALU /
+// transcendental unit of a SIMD are never busy at the same time: the kernels above take MFMA time + VALU time per tile
+// (~1400 cycles per 32-query x 64-key wave-tile = 640 + ~700).  One wave per SIMD does not fix it either
+// (mk_attention_w1.hip): a lone wave issues a v_exp_f32 only every ~16 cycles (two waves: ~9), and at head_dim 64 there
+// are 1.6 exponentials per MFMA.  Here the two rows run HALF A TILE APART, as the ping-pong GEMM's wave-rows do:
+//     slot 2t   : row 0  M(t) = { O += V(t-1).P(t-1), l += 1.P(t-1), S'(t) = K(t).Q^T - m }   (20 MFMAs, matrix pipe)
+//                 row 1  X(t-1) = { max S', (rare) re-base, P = exp2(S') -> 16 bit }          (VALU / transcendental)
+//     slot 2t+1 : row 0  X(t) ,  row 1  M(t)
+// with a workgroup barrier at every slot boundary.  K(u+1) and V(u) are fetched by LDS-DMA (one K piece and one V piece per
+// wave, SGPR-addressed, invisible to hipcc's vmcnt) at the start of the even slot 2u and waited for at the end of slot
+// 2u+1; K(t) is read in slots 2t, 2t+1 and V(t) in slots 2t+2, 2t+3, so two buffers of each are enough.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                             const T* __restrict__ vt, T* __restrict__ out, int ldo, int heads,
+                                                             int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K[2] | Vt[2]
+  char* const sKb = smem;
+  char* const sVb = smem + 2 * KV_TILE_BYTES;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = wave >> 2;
+  const AttnBlock ab = attn_block();
+  const int head = ab.head, img = ab.img;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = ab.qblk * 256 + wave * 32;
+  const int j = lane & 31, hi = lane >> 5;
+  const int nkt = (ntok + 63) >> 6;
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 qraw[4];
+  {
+    int qrow = q0 + j;
+    qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qraw[ks] = *(const u32x4*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  }
+  // the only loads hipcc knows about: waited for HERE (at their first use inside the loop it would emit a vmcnt(0) per
+  // iteration, which also drains the LDS-DMA pieces it does not know about)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]) :: "memory");
+  V8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(V8, qraw[ks]);
+  V8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+
+  // LDS-DMA: 8 one-KiB pieces per operand tile, one per wave
+  const int srow = lane >> 3, sp = lane & 7;
+  const int pr = wave * 8 + srow;
+  const unsigned voffK = (unsigned)((pr * 64 + swz8(pr, sp) * 8) * (int)sizeof(T));
+  const unsigned voffV = (unsigned)((pr * ntok_pad + swz8(pr, sp) * 8) * (int)sizeof(T));
+  auto dma_k = [&](int tile) { glds16_sv(Kh + (long long)tile * 4096, voffK, sKb + (tile & 1) * KV_TILE_BYTES + wave * 1024); };
+  auto dma_v = [&](int tile) { glds16_sv(Vh + tile * 64, voffV, sVb + (tile & 1) * KV_TILE_BYTES + wave * 1024); };
+  // start of the even slot 2u: K(u+1) and V(u) go out (every wave its piece)
+  auto dma_even = [&](int u) {
+    if (u + 1 < nkt) dma_k(u + 1);
+    if (u < nkt) dma_v(u);
+  };
+  auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+  auto bar_landed = [&]() {   // end of an odd slot: this wave's pieces of the next even slot's tiles have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  f32x16 o[2], lsum, negm, s[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    o[0][i] = o[1][i] = 0.f;
+    lsum[i] = 0.f;
+    negm[i] = 0.f;          // m = 0 to start with; the first tile re-bases
+    s[0][i] = s[1][i] = 0.f;
+  }
+  V8 pf[4];
+  float m_run = 0.f;
+  bool first = true;
+
+  // M(t): the matrix-pipe half of tile t (P.V and the row sums of tile t-1, S' of tile t)
+  auto mphase = [&](int t) {
+    __builtin_amdgcn_s_setprio(1);
+    if (t > 0) {
+      const char* sV = sVb + ((t - 1) & 1) * KV_TILE_BYTES;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int r = dt * 32 + j;
+          const V8 vf = *(const V8*)(sV + r * 128 + swz8(r, s4 * 2 + hi) * 16);
+          o[dt] = Lp<T>::mma32(vf, pf[s4], o[dt]);
+        }
+        lsum = Lp<T>::mma32(ones, pf[s4], lsum);   // row sums on the matrix pipe
+      }
+    }
+    if (t < nkt) {
+      const char* sK = sKb + (t & 1) * KV_TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int r = kb * 32 + j;
+          const V8 kf = *(const V8*)(sK + r * 128 + swz8(r, ks * 2 + hi) * 16);
+          s[kb] = Lp<T>::mma32(kf, qf[ks], ks == 0 ? negm : s[kb]);   // S' = K.Q^T - m
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // X(t): the VALU half of tile t
+  auto xphase = [&](int t) {
+    if (t == nkt - 1 && (ntok & 63)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= ntok) s[kb][r] = -1e30f;
+        }
+    }
+    float t8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s[0][r], s[0][r + 8]), fmaxf(s[1][r], s[1][r + 8]));
+    float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+    mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
+    if (__any(mx > ATT_REBASE_THR) || first) {   // wave-uniform, rare after the first tile
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile
+      const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+        lsum[i] *= alpha;
+        s[0][i] -= shift;
+        s[1][i] -= shift;
+      }
+      m_run += shift;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -m_run;
+      first = false;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[s4][e] = (T)__builtin_amdgcn_exp2f(s[s4 >> 1][(s4 & 1) * 8 + e]);
+  };
+
+  // prologue: K(0)
+  dma_k(0);
+  bar_landed();
+  if (row == 0) {
+    for (int t = 0; t < nkt; ++t) {
+      dma_even(t);      // slot 2t
+      mphase(t);
+      bar();
+      xphase(t);        // slot 2t+1
+      bar_landed();
+    }
+    dma_even(nkt);      // slot 2 nkt (nothing left to fetch: keeps the code symmetric)
+    mphase(nkt);
+    bar();
+  } else {
+    dma_even(0);        // slot 0: this row idles, its share of the pieces goes out all the same
+    bar();
+    for (int t = 0; t < nkt; ++t) {
+      mphase(t);        // slot 2t+1
+      bar_landed();
+      dma_even(t + 1);  // slot 2t+2
+      xphase(t);
+      bar();
+    }
+    mphase(nkt);        // slot 2 nkt + 1
   }
 
   const float inv = 1.0f / lsum[0];   // every accumulator row of ones.P^T holds the full row sum of this lane's query
@@ -384,8 +594,14 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
                                        std::is_same<T, __bf16>::value ? MK_BF16 : MK_F16, st))
     mode = 2;
   if (mode == 7) {
+  } else if (mode == 8) {
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<T>), dim3((ntok + 255) / 256, heads, nimg), dim3(512), 0, st, (const T*)q, (const T*)k,
+                       (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   } else if (mode == 4) {
-    hipLaunchKernelGGL((attn_fwd_lean_kernel<T>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<T, true>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  } else if (mode == 9) {
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<T, false>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   } else if (mode == 2) {
     hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
@@ -399,8 +615,8 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }  // namespace
 
 extern "C" int mk_attn_set_mode(int mode) {
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 7,
-               "mk_attn_set_mode: 0 automatic, 1 = 32 q/wave, 2 = 64 q/wave, 4 = VALU-lean, 7 = one wave per SIMD");
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 7 || mode == 8 || mode == 9,
+               "mk_attn_set_mode: 0 automatic, 1 = 32 q/wave, 2 = 64 q/wave, 4 = VALU-lean, 7 = one wave per SIMD, 8 = ping-pong");
   g_attn_mode = mode;
   return MK_OK;
 }

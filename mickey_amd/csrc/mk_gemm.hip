@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   if (NS == 3 && nk > 1) st.issue(p, smem + STAGE_BYTES, smem + STAGE_BYTES + A_BYTES, 1);
   // folded LayerNorm (consumer): row parameters of the tile into LDS while the first stage is in flight
   float2* lnp = (float2*)(smem + NS * STAGE_BYTES);
-  if (AMODE == A_DENSE && p.ln_stats && tid < 2 * BM) ln_params_to_lds<BM, 2 * BM>(p, m0, tid, lnp);
+  if (AMODE == A_DENSE && p.ln_stats && tid < 2 * BM) ln_params_to_lds<BM, 2 * BM>(p, m0, tid, lnp, p.ln_shift_out != nullptr && n0 == 0);
   f32x4 acc[WMF][4];
 #pragma unroll
   for (int i = 0; i < WMF; ++i)
@@ -264,27 +264,27 @@ int mk_gemm_patch_embed(const void* A, int lda, const void* W, int ldw, const fl
 // ---- LayerNorm folded into the GEMMs around it (reference block.py:84-88,105-106: x + ls(f(norm(x)))) ----
 // producer: the residual / patch-embed epilogue also emits the new rows in 16 bit (raw) and their partial statistics;
 // consumer: A = those raw rows, W = W.diag(ln_weight), and the epilogue applies rstd / mean per row.
-static int ln_consumer_args(GemmParams& p, const float* colsum, const float* stats, float eps, const char* who) {
+static int ln_consumer_args(GemmParams& p, const float* colsum, const float* stats, float eps, float* shift_out, const char* who) {
   MK_CHECK_ARG(colsum && stats && p.bias, "%s: colsum, stats and bias are required", who);
   MK_CHECK_ARG(p.lda == p.K, "%s: the normalised width is K: lda must equal K", who);
-  p.ln_colsum = colsum; p.ln_stats = stats; p.ln_nslot = p.K / 64; p.ln_eps = eps;
+  p.ln_colsum = colsum; p.ln_stats = stats; p.ln_nslot = p.K / 64; p.ln_eps = eps; p.ln_shift_out = shift_out;
   return MK_OK;
 }
 
 int mk_gemm_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
-               float eps, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream) {
+               float eps, float* shift_out, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream) {
   GemmParams p = {};
   p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = ldc; p.out_lp = out;
   if (int e = check_common(p, dtype)) return e;
   MK_CHECK_ARG(lda % 8 == 0 && ldc % 4 == 0 && ldc >= N && out && (act == MK_ACT_NONE || act == MK_ACT_GELU), "mk_gemm_ln: bad args");
-  if (int e = ln_consumer_args(p, colsum, stats, eps, "mk_gemm_ln")) return e;
+  if (int e = ln_consumer_args(p, colsum, stats, eps, shift_out, "mk_gemm_ln")) return e;
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
 int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
-                   float eps, void* q, void* k, void* vt, int nimg, int ntok, int ntok_pad, int heads, float qscale, int dtype,
-                   mk_stream_t stream) {
+                   float eps, float* shift_out, void* q, void* k, void* vt, int nimg, int ntok, int ntok_pad, int heads,
+                   float qscale, int dtype, mk_stream_t stream) {
   GemmParams p = {};
   const int D = heads * 64;
   p.A = A; p.W = W; p.M = nimg * ntok; p.N = 3 * D; p.K = D; p.lda = lda; p.ldw = ldw;
@@ -292,17 +292,17 @@ int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* 
   p.ntok = ntok; p.ntok_pad = ntok_pad; p.heads = heads; p.qscale = qscale;
   if (int e = check_common(p, dtype)) return e;
   MK_CHECK_ARG(q && k && vt && ntok_pad % 64 == 0 && ntok_pad >= ntok && lda % 8 == 0, "mk_gemm_qkv_ln: bad args");
-  if (int e = ln_consumer_args(p, colsum, stats, eps, "mk_gemm_qkv_ln")) return e;
+  if (int e = ln_consumer_args(p, colsum, stats, eps, shift_out, "mk_gemm_qkv_ln")) return e;
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
 int mk_gemm_ls_residual_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* gamma, void* xh,
-                           void* xl, int ldxs, float* stats, float* x_f32_out, int ldx, int M, int N, int K, int dtype,
-                           mk_stream_t stream) {
+                           void* xl, int ldxs, float* stats, const float* shift_in, float* x_f32_out, int ldx, int M, int N,
+                           int K, int dtype, mk_stream_t stream) {
   GemmParams p = {};
   p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
   p.epi = MK_EPI_LS_RESIDUAL; p.bias = bias; p.gamma = gamma; p.out_f32 = x_f32_out; p.ldc = ldx;
-  p.xh = xh; p.xl = xl; p.ldxs = ldxs; p.stats_out = stats; p.nslot_out = N / 64;
+  p.xh = xh; p.xl = xl; p.ldxs = ldxs; p.stats_out = stats; p.nslot_out = N / 64; p.ln_shift_in = shift_in;
   if (int e = check_common(p, dtype)) return e;
   MK_CHECK_ARG(bias && gamma && lda % 8 == 0 && lda >= K, "mk_gemm_ls_residual_ln: bad args");
   MK_CHECK_ARG(xh && xl && N % 64 == 0 && ldxs % 8 == 0 && ldxs >= N, "mk_gemm_ls_residual_ln: xh / xl / N %% 64");

@@ -61,6 +61,14 @@ struct GemmParams {
   const float* ln_colsum; // [N]: sum_k W'[n][k] of the 16-bit-rounded folded weights
   int ln_nslot;           // K / 64
   float ln_eps;
+  // ---- row centring of the split stream.  LayerNorm does not see a constant added to all channels of a row, and nothing
+  // but LayerNorm (norm1 / norm2 / the final norm) ever reads the residual stream: the stream may carry any per-row offset.
+  // The consumer knows each row's mean (from the statistics) and publishes it (ln_shift_out, written by the tiles of the
+  // first column); the NEXT producer subtracts it while it adds the branch output (ln_shift_in): rows stay centred to within
+  // one residual update, so the 16-bit hi plane rounds (x - mean) rather than x -- the operand rounding of the folded form
+  // is then that of a LayerNorm OUTPUT (2^-9 |x - mean| for bf16), whatever the common-mode level of the row.
+  float* ln_shift_out;        // [M], consumer side; null = not published
+  const float* ln_shift_in;   // [M], producer side; null = no centring
 };
 
 // Row statistics of the folded LayerNorm, ONE summation order in every epilogue (so that a row's statistics -- hence its
@@ -119,8 +127,9 @@ struct LnRowLoads16 {
     }
   }
   // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight
+  // publish: this tile belongs to the first tile column and writes the row means for the next producer (rows m0 ...)
   template <int YOUNGER>
-  __device__ __forceinline__ void finish(const GemmParams& p, int tid, float2* prm) {
+  __device__ __forceinline__ void finish(const GemmParams& p, int tid, float2* prm, int m0 = 0, bool publish = false) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -136,40 +145,82 @@ struct LnRowLoads16 {
       double var = (double)q * (1.0 / 1024.0) - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const float rstd = 1.0f / sqrtf((float)var + p.ln_eps);
-      if ((lane & 7) == 0) prm[wave * 32 + j * 8 + (lane >> 3)] = make_float2(rstd, -(float)mean * rstd);
+      if ((lane & 7) == 0) {
+        const int r = wave * 32 + j * 8 + (lane >> 3);
+        prm[r] = make_float2(rstd, -(float)mean * rstd);
+        if (publish && m0 + r < p.M) p.ln_shift_out[m0 + r] = (float)mean;
+      }
     }
   }
 };
 
+// Producer prologue of the row centring: the tile's BM row shifts into LDS (zeros without centring), loaded by inline asm
+// BEFORE the first LDS-DMA pieces and written after them (a load hipcc knows about would be waited for with vmcnt(0)).
+struct ShiftLoad {
+  float v;
+  __device__ __forceinline__ void issue(const GemmParams& p, int m0, int tid, int BM) {
+    v = 0.f;
+    if (p.ln_shift_in && tid < BM) {
+      int m = m0 + tid;
+      m = m < p.M ? m : p.M - 1;
+      const float* a = p.ln_shift_in + m;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(a) : "memory");
+    }
+  }
+  template <int YOUNGER>
+  __device__ __forceinline__ void finish(int tid, int BM, float* shl) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(YOUNGER) : "memory");
+    if (tid < BM) shl[tid] = v;
+  }
+};
+
+// Generic widths (and the 128x128 kernel).  ONE summation order with LnRowLoads16: a balanced binary tree over the slots in
+// natural order, in fp32 -- pairs (2c, 2c+1), quads, eights, then the two halves -- with absent slots as zeros (x + 0 = x), so a
+// row's (rstd, mean) do not depend on which schedule normalises it.  Up to 16 slots (D <= 1024) take the tree; wider rows
+// fall back to a sequential sum per half (their own, still schedule-independent, order).
 template <int BM, int NT>
-__device__ __forceinline__ void ln_params_to_lds(const GemmParams& p, int m0, int tid, float2* prm) {
+__device__ __forceinline__ void ln_params_to_lds(const GemmParams& p, int m0, int tid, float2* prm, bool publish = false) {
   static_assert(NT == 2 * BM, "two threads per row");
   const int r = tid >> 1, h = tid & 1;
   int m = m0 + r;
   m = m < p.M ? m : p.M - 1;
-  // thread h of the pair takes the lower / upper half of the row's slots: up to 8 independent 8-byte loads in flight
-  // (a loop with one load per iteration serialises on the L2 round trip: measured +3 us per 256x256 tile)
-  const int per = (p.ln_nslot + 1) >> 1;
-  const int lo = h * per, hi = min(p.ln_nslot, lo + per);
   const float2* st = (const float2*)p.ln_stats + (long long)m * p.ln_nslot;
-  float s = 0.f, q = 0.f;
-  for (int i0 = lo; i0 < hi; i0 += 8) {
+  float s, q;
+  if (p.ln_nslot <= 16) {
+    // thread h of the pair takes slots 8h .. 8h+7: 8 independent 8-byte loads in flight
     float2 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = i0 + j < hi ? st[i0 + j] : make_float2(0.f, 0.f);
+    for (int j = 0; j < 8; ++j) v[j] = 8 * h + j < p.ln_nslot ? st[8 * h + j] : make_float2(0.f, 0.f);
+    const float s01 = v[0].x + v[1].x, s23 = v[2].x + v[3].x, s45 = v[4].x + v[5].x, s67 = v[6].x + v[7].x;
+    const float q01 = v[0].y + v[1].y, q23 = v[2].y + v[3].y, q45 = v[4].y + v[5].y, q67 = v[6].y + v[7].y;
+    s = (s01 + s23) + (s45 + s67);
+    q = (q01 + q23) + (q45 + q67);
+  } else {
+    const int per = (p.ln_nslot + 1) >> 1;
+    const int lo = h * per, hi = min(p.ln_nslot, lo + per);
+    s = q = 0.f;
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+      float2 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s += v[j].x;
-      q += v[j].y;
+      for (int j = 0; j < 8; ++j) v[j] = i0 + j < hi ? st[i0 + j] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s += v[j].x;
+        q += v[j].y;
+      }
     }
   }
-  const double sd = (double)s + (double)__shfl_xor(s, 1, 64), qd = (double)q + (double)__shfl_xor(q, 1, 64);
+  s += __shfl_xor(s, 1, 64);   // fp32, as the DPP tree of LnRowLoads16 (commutative: both threads hold the same bits)
+  q += __shfl_xor(q, 1, 64);
   const double invn = 1.0 / (64.0 * p.ln_nslot);
-  const double mean = sd * invn;
-  double var = qd * invn - mean * mean;
+  const double mean = (double)s * invn;
+  double var = (double)q * invn - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const float rstd = 1.0f / sqrtf((float)var + p.ln_eps);
-  if (h == 0) prm[r] = make_float2(rstd, -(float)mean * rstd);
+  if (h == 0) {
+    prm[r] = make_float2(rstd, -(float)mean * rstd);
+    if (publish && m0 + r < p.M) p.ln_shift_out[m0 + r] = (float)mean;
+  }
 }
 
 template <typename T>
@@ -316,6 +367,8 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
         tok1 = 1 + (m - img * p.npatch);
         xrow = (long long)img * (p.npatch + 1) + tok1;
       }
+      // row centring: the mean this row had before the update (published by the consumer in between) comes off
+      const float shv = (EPI == MK_EPI_LS_RESIDUAL && p.ln_shift_in && mok) ? p.ln_shift_in[m] : 0.f;
       float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // per column quad fg + 4 ni (see quad_stats)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
@@ -331,6 +384,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
           r += gm * v;
+          r -= shv;
           v = r;
         } else {
           v += *(const f32x4*)(p.pos + (long long)tok1 * p.N + n);
@@ -704,6 +758,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
             x = xr[half][it];
           }
           x += gm * val;
+          if (SPLIT) x -= ((const float*)lnp)[wm * 128 + half * 64 + r];   // row centring (zeros when off): kernel prologue
           if (!SPLIT || fin) {
             if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
           } else {
@@ -758,13 +813,13 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8
   if constexpr (KIND == 2 || KIND == 3) {
     const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;   // workgroup-uniform
     if (KIND == 3) {   // LS_RESIDUAL with fp32 rows out (last block)
-      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     } else if (p.epi == MK_EPI_PATCH) {
       if (interior) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
       else epilogue_impl<T, 8, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     } else {
-      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, false>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     }
   } else if constexpr (KIND == 1) {

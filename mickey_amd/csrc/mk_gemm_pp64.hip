@@ -215,13 +215,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
 #endif
   LnRowLoads16 lnl;
   if (ln_fast) lnl.issue(p, m0, tid);
+  // folded LayerNorm (producer): the row shifts of the tile (row centring, zeros when off) take the same route into LDS
+  constexpr bool PRODUCER = AMODE == A_DENSE && (KIND == 2 || KIND == 3);
+  ShiftLoad shl;
+  if constexpr (PRODUCER) shl.issue(p, m0, tid, 256);
   dma_a(0);
   dma_w(0);
   if constexpr (A_IN_MFMA_SLOT) dma_a(1);
-  if (ln_fast) lnl.template finish<12>(p, tid, (float2*)(smem + 2 * STAGE_BYTES));   // 12 DMA pieces are younger than the loads
+  const bool publish = ln && p.ln_shift_out != nullptr && n0 == 0;   // first tile column: the row means for the next producer
+  if (ln_fast) lnl.template finish<12>(p, tid, (float2*)(smem + 2 * STAGE_BYTES), m0, publish);   // 12 DMA pieces are younger than the loads
 #ifndef MK_LN_NO_SLOW
-  else if (ln) ln_params_to_lds<256, 512>(p, m0, tid, (float2*)(smem + 2 * STAGE_BYTES));
+  else if (ln) ln_params_to_lds<256, 512>(p, m0, tid, (float2*)(smem + 2 * STAGE_BYTES), publish);
 #endif
+  if constexpr (PRODUCER) shl.template finish<12>(tid, 256, (float*)(smem + 2 * STAGE_BYTES));
   if constexpr (A_IN_MFMA_SLOT) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {

@@ -85,6 +85,7 @@ class MickeyRelativePose(nn.Module):
         self.heads_fp32 = str(amd.get("HEADS_DTYPE", "same")).lower() in ("fp32", "float32")
         self.lean = bool(amd.get("LEAN", False))
         self.ln_fold = bool(amd.get("LN_FOLD", True))   # norm1 / norm2 folded into the GEMMs around them (16-bit modes)
+        self.ln_centre = bool(amd.get("LN_CENTRE", True))   # ... with the residual stream kept row-centred
         self.seed = int(amd.get("SEED", 0))
         # hipGraph replay of the whole forward for launch-bound batches: "auto" (<= GRAPH_MAX_IMAGES images), True, False
         self.graph_mode = amd.get("GRAPH", "auto")
@@ -210,7 +211,7 @@ class MickeyRelativePose(nn.Module):
                 raise RuntimeError("FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN is set but the checkpoint has no %s (the "
                                    "reference's strict load fails on this too)" % DUSTBIN_KEY)
             self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_fp32=self.heads_fp32,
-                                                ln_fold=self.ln_fold)
+                                                ln_fold=self.ln_fold, ln_centre=self.ln_centre)
         return self._dev_weights
 
     # ---- forward ---------------------------------------------------------------------------------

@@ -68,14 +68,16 @@ def gemm_qkv(a, w, bias, q, k, vt, nimg, ntok, ntok_pad, heads):
 
 
 # ---- LayerNorm folded into the GEMMs around it (mickey_hip.h: mk_gemm_*_ln) -------------------------------------------------
-def gemm_ls_residual_ln(a, w, bias, gamma, xh, xl, stats, x_out=None):
+def gemm_ls_residual_ln(a, w, bias, gamma, xh, xl, stats, x_out=None, shift=None):
     """(xh + xl) += gamma * (a @ w.T + bias) on the split residual stream (two 16-bit planes, x = hi + lo); stats[m, N // 64, 2]
     receives the per-slot (sum, sum of squares) of the new fp32 rows.  With x_out (fp32 [M, N]) the new rows are written there
-    instead and xh / xl / stats are left alone (last block)."""
+    instead and xh / xl / stats are left alone (last block).  shift (fp32 [M], as published by the consumer before): row
+    centring, the rows become x + branch - shift (mickey_hip.h)."""
     M, K = a.shape
     N = w.shape[0]
     call("mk_gemm_ls_residual_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(gamma), ptr(xh), ptr(xl),
-         xh.stride(0), ptr(stats), ptr(x_out), x_out.stride(0) if x_out is not None else N, M, N, K, dtype_code(a.dtype), stream())
+         xh.stride(0), ptr(stats), ptr(shift), ptr(x_out), x_out.stride(0) if x_out is not None else N, M, N, K,
+         dtype_code(a.dtype), stream())
 
 
 def gemm_patch_embed_ln(a, w, bias, pos, xh, xl, stats, nimg, npatch):
@@ -88,21 +90,22 @@ def cls_token_ln(cls, pos, xh, xl, stats, nimg, ntok, D):
     call("mk_cls_token_ln", ptr(cls), ptr(pos), ptr(xh), ptr(xl), ptr(stats), nimg, ntok, D, dtype_code(xh.dtype), stream())
 
 
-def gemm_ln(a, w, bias, colsum, stats, eps, act=ACT_NONE, out=None):
-    """out = act(LN(x) @ W.T + b) with a = the hi plane of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host)."""
+def gemm_ln(a, w, bias, colsum, stats, eps, act=ACT_NONE, out=None, shift_out=None):
+    """out = act(LN(x) @ W.T + b) with a = the hi plane of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host).
+    shift_out (fp32 [M]): receives every row's mean, for the next producer's row centring."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=a.dtype)
-    call("mk_gemm_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps), ptr(out),
-         out.stride(0), M, N, K, act, dtype_code(a.dtype), stream())
+    call("mk_gemm_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps), ptr(shift_out),
+         ptr(out), out.stride(0), M, N, K, act, dtype_code(a.dtype), stream())
     return out
 
 
-def gemm_qkv_ln(a, w, bias, colsum, stats, eps, q, k, vt, nimg, ntok, ntok_pad, heads):
+def gemm_qkv_ln(a, w, bias, colsum, stats, eps, q, k, vt, nimg, ntok, ntok_pad, heads, shift_out=None):
     qscale = (64.0 ** -0.5) * LOG2E
-    call("mk_gemm_qkv_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps), ptr(q),
-         ptr(k), ptr(vt), nimg, ntok, ntok_pad, heads, qscale, dtype_code(a.dtype), stream())
+    call("mk_gemm_qkv_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(colsum), ptr(stats), float(eps),
+         ptr(shift_out), ptr(q), ptr(k), ptr(vt), nimg, ntok, ntok_pad, heads, qscale, dtype_code(a.dtype), stream())
 
 
 def im2col_patch14(img, gh, gw, ldo, dtype):

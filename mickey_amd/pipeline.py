@@ -52,15 +52,18 @@ def encoder_forward(W, ws, img):
         xh = ws.get("xh", (M, D), lp, dev)
         xl = ws.get("xl", (M, D), lp, dev)
         st = ws.get("ln_stats", (M, D // 64, 2), torch.float32, dev)
+        # row centring (mickey_hip.h): every consumer publishes the rows' means, the producer after it takes them off -- the
+        # stream stays centred (LayerNorm, its only reader, cannot tell), so the raw hi plane rounds x - mean, not x
+        sh = ws.get("ln_shift", (M,), torch.float32, dev) if getattr(W, "ln_centre", True) else None
         ops.gemm_patch_embed_ln(a, W.patch_w, W.patch_b, pos, xh, xl, st, nimg, npatch)
         ops.cls_token_ln(W.cls, pos, xh, xl, st, nimg, ntok, D)
         last = len(W.blocks) - 1
         for bi, blk in enumerate(W.blocks):
-            ops.gemm_qkv_ln(xh, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads)
+            ops.gemm_qkv_ln(xh, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads, shift_out=sh)
             ops.flash_attn(q, k, vt, att, nimg, heads, ntok, pad)
-            ops.gemm_ls_residual_ln(att, blk.proj_w, blk.proj_b, blk.g1, xh, xl, st)
-            ops.gemm_ln(xh, blk.fc1_wf, blk.fc1_bf, blk.fc1_cs, st, 1e-6, act=ops.ACT_GELU, out=hid)
-            ops.gemm_ls_residual_ln(hid, blk.fc2_w, blk.fc2_b, blk.g2, xh, xl, st, x_out=x if bi == last else None)
+            ops.gemm_ls_residual_ln(att, blk.proj_w, blk.proj_b, blk.g1, xh, xl, st, shift=sh)
+            ops.gemm_ln(xh, blk.fc1_wf, blk.fc1_bf, blk.fc1_cs, st, 1e-6, act=ops.ACT_GELU, out=hid, shift_out=sh)
+            ops.gemm_ls_residual_ln(hid, blk.fc2_w, blk.fc2_b, blk.g2, xh, xl, st, x_out=x if bi == last else None, shift=sh)
     else:
         ops.gemm_patch_embed(a, W.patch_w, W.patch_b, pos, x, nimg, npatch)
         ops.cls_token(W.cls, pos, x, nimg, ntok, D)

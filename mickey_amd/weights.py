@@ -55,7 +55,7 @@ def fold_layernorm(w, b, ln_w, ln_b, lp_dtype):
     return wf, wf.float().sum(1), b.float() + w @ ln_b.float()
 
 
-def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=None, ln_fold=True):
+def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=None, ln_fold=True, ln_centre=True):
     """ln_fold: also prepare norm1 / norm2 folded into qkv / fc1 (16-bit operand types only): the encoder then runs without
     stand-alone LayerNorm passes (pipeline.encoder_forward)."""
     W = DeviceWeights() if W is None else W
@@ -72,6 +72,7 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     D, depth, heads = _arch_from_sd(sd, p)
     W.D, W.depth, W.heads = D, depth, heads
     W.ln_fold = bool(ln_fold) and lp_dtype != torch.float32 and D % 64 == 0
+    W.ln_centre = bool(ln_centre)   # row centring of the split residual stream (pipeline.encoder_forward)
     wp = torch.zeros((D, PATCH_K))
     wp[:, :588] = sd[p + "patch_embed.proj.weight"].float().reshape(D, 588)
     W.patch_w, W.patch_b = lp(wp), f32(sd[p + "patch_embed.proj.bias"])
@@ -104,10 +105,10 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False, ln_fold=True):
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False, ln_fold=True, ln_centre=True):
     """heads_fp32: keep the four head stacks' operands in fp32 (the reference always runs them in fp32,
     mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
-    W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold)
+    W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold, ln_centre=ln_centre)
     dev = device
     W.lp_heads = torch.float32 if heads_fp32 else lp_dtype
 

@@ -231,6 +231,30 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
             xh = calls[1][1][4]
             assert all(c[1][0] is xh for c in calls if c[0] in ("gemm_qkv_ln", "gemm_ln"))    # consumers read the hi plane
             assert calls[-1][1][0] is res[-1][2]["x_out"]                                     # the final norm reads the fp32 rows
+            # row centring: every consumer publishes into the buffer every producer reads
+            sh = res[0][2]["shift"]
+            assert sh is not None and sh.shape == (2 * 55,) and all(c[2]["shift"] is sh for c in res)
+            assert all(c[2]["shift_out"] is sh for c in calls if c[0] in ("gemm_qkv_ln", "gemm_ln"))
+            # bench.py's work / byte accounting accepts exactly these call signatures (a mismatch only shows on the GPU box)
+            import bench
+            prof = bench.StageProfiler()
+
+            class _Ops:
+                pass
+            fake = _Ops()
+            for nm in ("gemm", "gemm_ls_residual", "gemm_qkv", "gemm_patch_embed", "gemm_ln", "gemm_qkv_ln", "gemm_ls_residual_ln",
+                       "gemm_patch_embed_ln", "flash_attn", "conv3x3", "gemm_grouped", "layernorm", "dual_softmax", "sinkhorn",
+                       "exprace_topk", "gather_backproject", "ransac_hypotheses", "refine_pose"):
+                setattr(fake, nm, lambda *a, **k: None)
+            ev = type("E", (), {"record": lambda self: None, "elapsed_time": lambda self, o: 1.0})
+            monkeypatch.setattr(torch.cuda, "Event", lambda enable_timing=True: ev())
+            prof.wrap(fake)
+            prof.on = True
+            for nm, a, k in calls:
+                if hasattr(fake, nm):
+                    getattr(fake, nm)(*a, **k)
+            stages, by = prof.summary(1)
+            assert by["encoder_gemm"]["launches"] == 1 + 4 * W.depth and by["encoder_gemm"]["bytes"] > 0
         else:
             assert names == ["im2col", "gemm_patch_embed", "cls_token"] + \
                 ["layernorm", "gemm_qkv", "flash_attn", "gemm_ls_residual", "layernorm", "gemm", "gemm_ls_residual"] * W.depth + ["layernorm"]

@@ -14,6 +14,6 @@ M, N, K = 3878 * 16, 1024, 4096
 a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
 w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
 out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
-for _ in range(4):
+for _ in range(int(os.environ.get("REPS", "4"))):
     ops.gemm(a, w, None, out=out)
 torch.cuda.synchronize()
