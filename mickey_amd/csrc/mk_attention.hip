@@ -36,6 +36,7 @@ namespace {
 using namespace mk;
 
 constexpr int KV_TILE_BYTES = 64 * 64 * 2;  // 8 KiB
+constexpr float ATT_REBASE_THR = 8.0f;    // lean softmax: the running maximum is re-based when a tile exceeds it by 2^8
 
 // XCD-aware decode of the workgroup id.  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so
 // with the natural (query block, head, image) grid the 16 query blocks of one (image, head) land on all 8 XCDs and every
@@ -221,6 +222,168 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// Production kernel (mode 9 / automatic): QB sub-blocks of 32 queries per wave, the lean softmax of attn_fwd_lean_kernel with
+// the row sums on the VALU.  What decides between variants on this part is ENERGY per tile, not cycles: the chip runs every
+// attention kernel (and the GEMM) at its power limit -- profiles/r03_pmc_clock_attention_gemm.json: variants that need fewer
+// cycles run at a lower clock and finish at the same wall time -- so the kernel that issues the least work wins:
+//   * no subtraction of the running maximum (folded into the MFMA accumulator init), no per-tile rescale of O (re-base only
+//     when a tile exceeds the maximum by 2^8), 16 MFMAs per 32 x 64 tile (the matrix-pipe row sums of the lean kernel were a
+//     fifth of its matrix work: 805-825 -> 885 TFLOP/s when they went back to 32 fp32 adds);
+//   * QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and a workgroup covers 256 queries per staged tile.
+template <typename T, int QB>
+__global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                              const T* __restrict__ vt, T* __restrict__ out,
+                                                                              int ldo, int heads, int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlock ab = attn_block();
+  const int head = ab.head, img = ab.img;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = ab.qblk * (128 * QB) + wave * (32 * QB);
+  const int j = lane & 31, hi = lane >> 5;
+  const bool wave_has_queries = q0 < ntok;   // pad-only waves of the last query block stage K/V and keep the barriers, nothing else
+
+  V8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qrow = q0 + qb * 32 + j;
+    qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 16 + hi * 8);
+  }
+  const int srow = lane >> 3, sp = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * KV_TILE_BYTES;
+    char* sV = sK + KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ii = wave * 2 + t;
+      const int r = ii * 8 + srow;
+      glds16(Kh + (long long)(kt * 64 + r) * 64 + swz8(r, sp) * 8, sK + ii * 1024);
+      glds16(Vh + (long long)r * ntok_pad + kt * 64 + swz8(r, sp) * 8, sV + ii * 1024);
+    }
+  };
+
+  f32x16 o[QB][2], negm[QB];
+  float m_run[QB], l_run[QB];   // l_run: this lane's share of the row sum (lanes j and j + 32 are added at the end)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o[qb][0][i] = o[qb][1][i] = 0.f;
+      negm[qb][i] = 0.f;      // m = 0 to start with; the first tile re-bases
+    }
+    m_run[qb] = l_run[qb] = 0.f;
+  }
+  bool first = true;
+
+  const int nkt = (ntok + 63) >> 6;
+  stage(0, 0);
+  auto kv_tile = [&](const int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;   // compile-time: only the peeled final tile carries the key mask
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!LAST) stage((kt + 1) & 1, kt + 1);
+    if (!wave_has_queries) return;
+    const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+    const char* sV = sK + KV_TILE_BYTES;
+
+    f32x16 s[QB][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = kb * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 2 + hi) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = Lp<T>::mma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][kb]);   // S' = K.Q^T - m
+      }
+    }
+    V8 pf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (LAST && (ntok & 63)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= ntok) s[qb][kb][r] = -1e30f;
+          }
+      }
+      float t8[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s[qb][0][r], s[qb][0][r + 8]), fmaxf(s[qb][1][r], s[qb][1][r + 8]));
+      float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+      mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
+      if (__any(mx > ATT_REBASE_THR) || first) {   // wave-uniform, rare after the first tile: re-base m to this tile's maximum
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile
+        const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          o[qb][0][i] *= alpha;
+          o[qb][1][i] *= alpha;
+          s[qb][0][i] -= shift;
+          s[qb][1][i] -= shift;
+        }
+        l_run[qb] *= alpha;
+        m_run[qb] += shift;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
+      }
+      float rs4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 32-deep dependent add chain
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(s[qb][s4 >> 1][(s4 & 1) * 8 + e]);
+          pf[qb][s4][e] = (T)pv;
+          rs4[e & 3] += pv;
+        }
+      l_run[qb] += (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+    }
+    first = false;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int row = dt * 32 + j;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[qb][dt] = Lp<T>::mma32(vf, pf[qb][s4], o[qb][dt]);
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt - 1; ++kt) kv_tile(kt, std::false_type{});
+  kv_tile(nkt - 1, std::true_type{});
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float inv = 1.0f / (l_run[qb] + __shfl_xor(l_run[qb], 32, 64));
+    const int qi = q0 + qb * 32 + j;
+    if (qi < ntok) {
+      T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          V4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (T)(o[qb][dt][r4 * 4 + e] * inv);
+          *(V4*)(orow + dt * 32 + r4 * 8 + hi * 4) = w;
+        }
+    }
+  }
+}
+
 // VALU-lean variant (32 queries per wave).  A wave64 VALU instruction costs ~4 issue cycles and a 32-cycle MFMA hides
 // only a handful of them, so the softmax (~170 VALU instructions per 16 MFMAs) bounds the kernels above.  Here:
 //  * the running maximum is folded into the QK^T accumulator init: S' = K.Q^T + (-m) comes out of the MFMA already
@@ -230,7 +393,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 //  * the row sums are computed on the matrix pipe (ones . P^T, 4 extra MFMAs per tile) instead of 32 VALU adds; they
 //    sum the same 16-bit P that multiplies V, and need no cross-lane exchange.
 // Per tile and wave: 20 MFMAs and ~70 VALU instructions (16 max3, 32 exp, 16 cvt).
-constexpr float ATT_REBASE_THR = 8.0f;
 
 // MSUM: row sums on the matrix pipe (ones . P^T); false: as 32 fp32 adds per tile on the VALU.  The part runs this kernel at
 // its POWER limit (profiles/r03_pmc_clock.json: every attention variant ends at the same wall time, the ones that need fewer
@@ -603,6 +765,12 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
   } else if (mode == 9) {
     hipLaunchKernelGGL((attn_fwd_lean_kernel<T, false>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  } else if (mode == 10) {
+    hipLaunchKernelGGL((attn_fwd_fold_kernel<T, 1>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  } else if (mode == 11) {
+    hipLaunchKernelGGL((attn_fwd_fold_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   } else if (mode == 2) {
     hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
@@ -615,7 +783,7 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }  // namespace
 
 extern "C" int mk_attn_set_mode(int mode) {
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 7 || mode == 8 || mode == 9,
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 7 || mode == 8 || mode == 9 || mode == 10 || mode == 11,
                "mk_attn_set_mode: 0 automatic, 1 = 32 q/wave, 2 = 64 q/wave, 4 = VALU-lean, 7 = one wave per SIMD, 8 = ping-pong");
   g_attn_mode = mode;
   return MK_OK;

@@ -369,7 +369,7 @@ def test_layernorm(D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("mode", [0, 1, 2, 4, 7, 8, 9])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])
 def test_flash_attention(dtype, ntok, nimg, heads, mode):
     """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the large-grid kernel in auto mode; modes: 1 / 2 = 32 / 64
