@@ -122,6 +122,9 @@ int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const
                            void* xl, float* stats, int nimg, int npatch, int D, int K, int dtype, mk_stream_t stream);
 int mk_cls_token_ln(const float* cls, const float* pos, void* xh, void* xl, float* stats, int nimg, int ntok, int D, int dtype,
                     mk_stream_t stream);
+/* Row centring of a freshly produced stream (after mk_gemm_patch_embed_ln + mk_cls_token_ln): every row of hi + lo gets its
+ * own mean subtracted in place and its statistics rewritten, so that the first consumer also meets centred rows. */
+int mk_recentre_split(void* xh, void* xl, float* stats, long long rows, int D, int dtype, mk_stream_t stream);
 /* consumers: mk_gemm (bias, optional GELU, 16-bit output) and mk_gemm_qkv with A = the hi plane [M, K] (lda == K) */
 int mk_gemm_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const float* colsum, const float* stats,
                float eps, float* shift_out, void* out, int ldc, int M, int N, int K, int act, int dtype, mk_stream_t stream);

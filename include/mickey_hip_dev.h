@@ -18,11 +18,10 @@ extern "C" {
  * tiling off / on. */
 int mk_gemm_set_tile(int mode);
 
-/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (the large-grid kernel for >= 512 workgroups of 256 queries, 4 for
- * small grids), 1 = 32 queries/wave, 2 = 64 queries/wave (both two waves per SIMD), 4 = VALU-lean (max folded into the
- * MFMA accumulator init, row sums on the matrix pipe), 7 = one wave per SIMD (64 queries per wave, K / V^T fragments and
- * the output accumulators in the accumulator register file, hand-placed MFMA / softmax interleave; problems with fewer
- * than 4 KV tiles run variant 2).  Process-wide; for benchmarks and tests. */
+/* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for >= 512 workgroups of 256 queries, 1 for smaller grids),
+ * 1 / 2 = the production kernel with 32 / 64 queries per wave (lean softmax: running maximum folded into the MFMA
+ * accumulator init, re-based only when a tile exceeds it by 2^8; fp32 row sums on the VALU), 3 = the classic online-softmax
+ * kernel (64 queries per wave; A/B partner).  Process-wide; for benchmarks and tests. */
 int mk_attn_set_mode(int mode);
 
 #ifdef __cplusplus

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mk_gemm_ls_residual_ln": ("i", "pipippppipppiiiiip"),
     "mk_gemm_patch_embed_ln": ("i", "pipipppppiiiiip"),
     "mk_cls_token_ln": ("i", "pppppiiiip"),
+    "mk_recentre_split": ("i", "ppplilp"),
     "mk_gemm_ln": ("i", "pipipppfppiiiiiip"),
     "mk_gemm_qkv_ln": ("i", "pipipppfppppiiiifip"),
     "mk_im2col_patch14": ("i", "plliiiipiip"),

@@ -23,10 +23,13 @@ LIBNAME = "libmickey_hip.so"
 ARCH = "gfx950"
 # per-file extra flags.  The attention kernel's softmax is VALU-bound: without NaN-honouring semantics fmaxf needs no
 # canonicalising v_max and folds into v_max3 (-18 % VALU instructions); its inputs are finite by construction.
-EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fassociative-math", "-fno-trapping-math"] +
+# NOT -fassociative-math: the 32 / 64-queries-per-wave instantiations must sum a row in the SAME order (pair i of a 32-pair
+# batch is bit-identical to the same pair run alone, tests/test_bench_config_gpu.py); free to re-associate, hipcc ordered
+# the row sums differently in the two -- and emitted 25 % more instructions.  -fno-slp-vectorize: left alone the row sums
+# become v_pk_add_f32, which beside MFMAs costs more than the two scalar adds it replaces (858 vs 9xx TFLOP/s).
+EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fno-trapping-math", "-fno-slp-vectorize"] +
                (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []) +
                (["-DMK_ATTN_LP_DBG"] if os.environ.get("MK_ATTN_LP_DBG") else []),
-               "mk_attention_w1.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fassociative-math", "-fno-trapping-math"],
                "mk_gemm_pp64.hip": (["-DMK_LN_ABL=%s" % os.environ["MK_LN_ABL"]] if os.environ.get("MK_LN_ABL") else []),
                "mk_gemm.hip": (["-DMK_PP64_ABLATIONS"] if os.environ.get("MK_PP64_ABLATIONS") else []) +
                               (["-DMK_GEMM_ABLATIONS"] if os.environ.get("MK_GEMM_ABLATIONS") else [])}

@@ -2,6 +2,7 @@
 // one wave per row, 16-byte loads/stores, wave64 shuffle reductions, values held in registers
 // between the statistics and the normalisation (single read of x).
 #include "mk_common.hpp"
+#include "mk_gemm_common.hpp"   // quad_stats / row16_sum: the one summation order of the row statistics
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -161,6 +162,56 @@ __global__ __launch_bounds__(64) void cls_ln_kernel(const float* __restrict__ cl
   }
 }
 
+// Row centring of a freshly produced split stream (mickey_hip.h, mk_recentre_split): every row gets its own mean taken off
+// -- LayerNorm, the stream's only reader, cannot tell -- so that the FIRST consumer of the folded LayerNorm (qkv of block 0, on
+// the patch embedding's output) also multiplies rows whose 16-bit hi plane rounds x - mean rather than x; from then on the
+// consumers publish the means and the producers keep the rows centred (GemmParams::ln_shift_*).  One wave per row, two reads
+// of the row (the second one hits L1 / L2); statistics in the epilogues' order (quad_stats + row16_sum).
+template <typename T>
+__global__ __launch_bounds__(256) void recentre_kernel(T* __restrict__ xh, T* __restrict__ xl, float* __restrict__ stats,
+                                                       long long rows, int D) {
+  using V4 = typename mk::Lp<T>::V4;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nslot = D >> 6;
+  T* ph = xh + row * D;
+  T* pl = xl + row * D;
+  const int quad = lane & 15, sub = lane >> 4;   // a 16-lane DPP row owns one 64-column slot at a time
+  float sum = 0.f;
+  for (int s0 = 0; s0 < nslot; s0 += 4) {
+    const int slot = s0 + sub;
+    if (slot < nslot) {
+      const V4 h = *(const V4*)(ph + slot * 64 + quad * 4), l = *(const V4*)(pl + slot * 64 + quad * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += (float)h[e] + (float)l[e];
+    }
+  }
+  const float mean = mk::wave_sum(sum) / (float)D;
+  for (int s0 = 0; s0 < nslot; s0 += 4) {
+    const int slot = s0 + sub;
+    const bool ok = slot < nslot;
+    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const V4 h = *(const V4*)(ph + slot * 64 + quad * 4), l = *(const V4*)(pl + slot * 64 + quad * 4);
+      V4 oh, ol;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = ((float)h[e] + (float)l[e]) - mean;
+        oh[e] = (T)x[e];
+        ol[e] = (T)(x[e] - (float)oh[e]);
+      }
+      *(V4*)(ph + slot * 64 + quad * 4) = oh;
+      *(V4*)(pl + slot * 64 + quad * 4) = ol;
+    }
+    float s, q;
+    mk::gemm::quad_stats(x, s, q);
+    s = mk::gemm::row16_sum(s);
+    q = mk::gemm::row16_sum(q);
+    if (ok && quad == 0) ((float2*)stats)[row * nslot + slot] = make_float2(s, q);
+  }
+}
+
 }  // namespace
 
 // ---- error string + version (host side) ---------------------------------------------------------------
@@ -237,6 +288,19 @@ int mk_cls_token_ln(const float* cls, const float* pos, void* xh, void* xl, floa
     hipLaunchKernelGGL((cls_ln_kernel<__bf16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, (__bf16*)xh, (__bf16*)xl, stats, ntok, D);
   else
     hipLaunchKernelGGL((cls_ln_kernel<_Float16>), dim3(nimg), dim3(64), 0, (hipStream_t)stream, cls, pos, (_Float16*)xh, (_Float16*)xl, stats, ntok, D);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+/* centre every row of a split stream on its own mean (in place) and rewrite its per-slot statistics */
+int mk_recentre_split(void* xh, void* xl, float* stats, long long rows, int D, int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(xh && xl && stats && rows > 0 && D > 0 && D % 64 == 0, "mk_recentre_split: bad args");
+  MK_CHECK_ARG(dtype == MK_BF16 || dtype == MK_F16, "mk_recentre_split: 16-bit dtypes only");
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == MK_BF16)
+    hipLaunchKernelGGL((recentre_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (__bf16*)xh, (__bf16*)xl, stats, rows, D);
+  else
+    hipLaunchKernelGGL((recentre_kernel<_Float16>), grid, dim3(256), 0, (hipStream_t)stream, (_Float16*)xh, (_Float16*)xl, stats, rows, D);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -90,6 +90,12 @@ def cls_token_ln(cls, pos, xh, xl, stats, nimg, ntok, D):
     call("mk_cls_token_ln", ptr(cls), ptr(pos), ptr(xh), ptr(xl), ptr(stats), nimg, ntok, D, dtype_code(xh.dtype), stream())
 
 
+def recentre_split(xh, xl, stats):
+    """Every row of the split stream (xh + xl) minus its own mean, in place; stats rewritten (mk_recentre_split)."""
+    rows, D = xh.shape
+    call("mk_recentre_split", ptr(xh), ptr(xl), ptr(stats), rows, D, dtype_code(xh.dtype), stream())
+
+
 def gemm_ln(a, w, bias, colsum, stats, eps, act=ACT_NONE, out=None, shift_out=None):
     """out = act(LN(x) @ W.T + b) with a = the hi plane of x, w = W * ln_weight, bias = b + W @ ln_bias (folded on the host).
     shift_out (fp32 [M]): receives every row's mean, for the next producer's row centring."""

@@ -57,6 +57,8 @@ def encoder_forward(W, ws, img):
         sh = ws.get("ln_shift", (M,), torch.float32, dev) if getattr(W, "ln_centre", True) else None
         ops.gemm_patch_embed_ln(a, W.patch_w, W.patch_b, pos, xh, xl, st, nimg, npatch)
         ops.cls_token_ln(W.cls, pos, xh, xl, st, nimg, ntok, D)
+        if sh is not None:
+            ops.recentre_split(xh, xl, st)   # the first consumer (qkv of block 0) meets centred rows too
         last = len(W.blocks) - 1
         for bi, blk in enumerate(W.blocks):
             ops.gemm_qkv_ln(xh, blk.qkv_wf, blk.qkv_bf, blk.qkv_cs, st, 1e-6, q, k, vt, nimg, ntok, pad, heads, shift_out=sh)

@@ -35,9 +35,11 @@ def _auto_schedules():
 
 def test_batch_invariance_of_the_benchmarked_forward(cfg):
     """Pair i of a B = 32 forward == the B = 1 forward of pair i with pair_base = i: features, score matrices AND the pose
-    (the samplers' Philox streams are keyed by the global pair index).  Schedules that the launcher would pick by problem
-    size are pinned, so that both batch sizes run the same kernels; with automatic selection the B = 1 run takes the
-    128x128 GEMM tiles and the small-grid attention variant, which round differently (checked below to the 16-bit floor)."""
+    (the samplers' Philox streams are keyed by the global pair index) -- with the schedules the launcher picks by itself:
+    the one-pair run takes 128x128 / 64x128 GEMM tiles and the 32-queries-per-wave attention instantiation, the 32-pair run
+    the 256x256 ping-pong GEMM and 64 queries per wave.  They agree bit for bit because every kernel family accumulates in one
+    k order, the folded LayerNorm's statistics have one summation order in every epilogue and prologue, and the attention
+    re-base decision is taken per aligned group of 32 queries in both instantiations."""
     import copy
     from mickey_amd import ops, synthetic as syn
     from mickey_amd.model import MickeyRelativePose
@@ -50,8 +52,8 @@ def test_batch_invariance_of_the_benchmarked_forward(cfg):
     model = model.cuda()
     B = 32
     batch = {k: v.to(dev) for k, v in syn.synthetic_batch(B=B, H=H, W=W, seed=1234).items()}
-    ops.gemm_set_tile(7)
-    ops.attn_set_mode(2)
+    ops.gemm_set_tile(0)
+    ops.attn_set_mode(0)
     model.reseed(calls=0)
     big = dict(batch)
     R, t = model(big)
@@ -65,9 +67,8 @@ def test_batch_invariance_of_the_benchmarked_forward(cfg):
         for k in keys:
             assert torch.equal(one[k][0], big[k][i]), (i, k, rel(one[k][0], big[k][i]))
         assert torch.equal(Ri[0], R[i]) and torch.equal(ti[0], t[i]) and torch.equal(one["inliers"][0], big["inliers"][i]), i
-    # automatic schedule selection (what bench.py and the callers run): same pair, same draws, different tile shapes
-    ops.gemm_set_tile(0)
-    ops.attn_set_mode(0)
+    # the classic online-softmax attention kernel (A/B partner) rounds differently: same pair to the 16-bit floor
+    ops.attn_set_mode(3)
     one = {k: v[13:14].contiguous() for k, v in batch.items()}
     one["pair_base"] = 13
     model.compute_correspondences(one)

@@ -210,7 +210,7 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
         return torch.zeros((img.shape[0] * gh * gw, ldo), dtype=dtype)
 
     for nm in ("gemm_patch_embed", "cls_token", "gemm_qkv", "flash_attn", "gemm_ls_residual", "gemm", "gemm_patch_embed_ln",
-               "cls_token_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_ln"):
+               "cls_token_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_ln", "recentre_split"):
         monkeypatch.setattr(ops, nm, rec(nm))
     monkeypatch.setattr(ops, "im2col_patch14", im2col)
     monkeypatch.setattr(ops, "layernorm", rec("layernorm", lambda x, w, b, eps, out=None, **k: out))
@@ -224,7 +224,7 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
         names = [c[0] for c in calls]
         assert (gh, gw) == (6, 9) and feat.shape == (2 * 54, 128)
         if fold:
-            assert names == ["im2col", "gemm_patch_embed_ln", "cls_token_ln"] + \
+            assert names == ["im2col", "gemm_patch_embed_ln", "cls_token_ln", "recentre_split"] + \
                 ["gemm_qkv_ln", "flash_attn", "gemm_ls_residual_ln", "gemm_ln", "gemm_ls_residual_ln"] * W.depth + ["layernorm"]
             res = [c for c in calls if c[0] == "gemm_ls_residual_ln"]
             assert [c[2].get("x_out") is not None for c in res] == [False] * (2 * W.depth - 1) + [True]

@@ -195,6 +195,24 @@ def test_full_forward_vs_oracle_vit_small(cfg, dtype):
     assert ((det - 1).abs() < 1e-4).all() or float(R.abs().sum()) == 0.0
 
 
+def test_row_centring_is_invisible(cfg):
+    """AMD.LN_CENTRE on / off: the encoder's residual stream with and without the per-row offset gives the same features to
+    the operand type's noise floor (LayerNorm is the only reader of the stream), and the fp16 forward with centring stays
+    inside the bounds of the reference golden."""
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
+    outs = {}
+    for centre in (True, False):
+        model, _ = _model(cfg, "fp16", LN_CENTRE=centre)
+        data = {k: v.to(dev) for k, v in batch.items()}
+        model.compute_correspondences(data)
+        outs[centre] = data
+    for k in ("dsc0", "scr0", "depth_kp0", "final_scores"):
+        assert rel(outs[True][k], outs[False][k]) < 2 * TOL[torch.float16][k.rstrip("01").replace("depth_kp", "depth")], k
+        assert not torch.equal(outs[True][k], outs[False][k])   # the switch does something
+
+
 def test_forward_determinism_lean_and_shapes(cfg):
     dev = _dev()
     from mickey_amd import synthetic as syn

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mickey_amd import ops  # noqa: E402
 from tools.bench_kernels import timeit  # noqa: E402
 
-modes = [int(t) for t in sys.argv[1:]] or [2, 4, 7]
+modes = [int(t) for t in sys.argv[1:]] or [1, 2, 3]
 dev = torch.device("cuda:0")
 nimg, heads, ntok, pad = 64, 16, 1939, 1984
 q = (torch.randn((nimg, heads, pad, 64), device=dev) * 0.2).bfloat16()

@@ -10,10 +10,9 @@ run() {  # tag, env assignment, script
   rm -rf /tmp/pc_$1
   env $2 NIMG=64 REPS=12 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pc_$1 -o p -- python $R/tools/$3 > /tmp/pc_$1.log 2>&1 || tail -3 /tmp/pc_$1.log
 }
+run attn1 ATTN_MODE=1 pmc_attn.py
 run attn2 ATTN_MODE=2 pmc_attn.py
-run attn4 ATTN_MODE=4 pmc_attn.py
-run attn7 ATTN_MODE=7 pmc_attn.py
-run attn8 ATTN_MODE=8 pmc_attn.py
+run attn3 ATTN_MODE=3 pmc_attn.py
 run gemm7 GEMM_MODE=7 pmc_gemm.py
 python - <<'PY'
 import collections, csv, glob, json, os
