@@ -307,6 +307,30 @@ int mk_train_ransac_masks(const float* X, const float* Y, const float* wts, cons
                           float th_ref, int num_ref, int num_corr, float* final_mask, int* idx_out, int* rounds, int nsets,
                           int it_ransac, int S, long long set_base, mk_stream_t stream);
 
+/* The DIFFERENTIABLE tail of the same function (loss_class.py:187-246), forward and backward: for every hypothesis
+ * hyp = r * it_ransac + h of every match set r (pair b = r / it_matches)
+ *   forward   weighted_procrustes(X_r, Y_r, mask_hyp) (loss/solvers.py:13-26,45-52: centroids with w / (sum|w| + 1e-16),
+ *             H = A_c^T (w B_c), H = U S V^T, R = V diag(1, 1, det(U V^T)) U^T, t = b_mean - a_mean R^T), the soft inlier score
+ *             sum_j sigmoid(5 / th (th - |R x_j + t - y_j|)) over all S matches (training_utils.py:55-61) and the loss:
+ *             loss_type 0 = compute_vcre_loss (loss_utils.py:41-69 with metrics.py:56-80: the 7 x 4 x 7 eye grid projected with
+ *             K0 / K1, clipped to [0, img_h], tanh(. / 80) with soft_clip), 1 = compute_pose_loss (:27-39);
+ *               out   float32 [nhyp, 4]  (loss_value, rot_angle_loss, trans_l1_loss, score)
+ *               Rt    float32 [nhyp, 12] (R row-major, t)
+ *               saved float32 [nhyp, 32] (U, V, S, det sign, centroids, sum of weights: for the backward pass)
+ *   backward  grad_out float32 [nhyp, 2] = dL/d(loss_value, score)  ->  gX, gY float32 [nsets, S, 3] = dL/dX, dL/dY, summed over
+ *             the it_ransac hypotheses of a set in hypothesis order (no atomics); the SVD is differentiated in closed form
+ *             (the adjoint of H -> R; finite for equal singular values, where torch.svd's backward is not);
+ *             work float32 [nhyp, 16] scratch.  mask, the poses and the intrinsics receive no gradient (the reference detaches
+ *             them: the mask comes out of torch.no_grad, :152-184).
+ * X, Y [nsets, S, 3], mask [nsets * it_ransac, S], Rgt [B, 9], tgt [B, 3], K0, K1 [B, 9] (VCRE only), S <= 1024. */
+int mk_train_tail_fwd(const float* X, const float* Y, const float* mask, const float* Rgt, const float* tgt, const float* K0,
+                      const float* K1, int nsets, int it_ransac, int S, int it_matches, float th_soft, int loss_type,
+                      int soft_clip, float img_h, float* out, float* Rt, float* saved, mk_stream_t stream);
+int mk_train_tail_bwd(const float* X, const float* Y, const float* mask, const float* Rgt, const float* tgt, const float* K0,
+                      const float* K1, int nsets, int it_ransac, int S, int it_matches, float th_soft, int loss_type,
+                      int soft_clip, float img_h, const float* Rt, const float* saved, const float* grad_out, float* work,
+                      float* gX, float* gY, mk_stream_t stream);
+
 /* REINFORCE bookkeeping of the same function (loss_class.py:251-261, a python loop over B*it_matches rows in the
  * reference): for row = b*it_matches + r, r ascending, and every sampled cell c = idx[row, s]:
  *   gradients[b, c] += loss_value[row];  gradients_b[b, c] += 1

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mk_pose_finalize": ("i", "ppppip"),
     "mk_train_ransac_masks": ("i", "pppppuupfiipppiiilp"),
     "mk_reinforce_scatter": ("i", "ppppiiilp"),
+    "mk_train_tail_fwd": ("i", "pppppppiiiifiifpppp"),
+    "mk_train_tail_bwd": ("i", "pppppppiiiifiifppppppp"),
 }
 
 # development knobs (include/mickey_hip_dev.h): process-wide schedule selectors for benchmarks / tests, never called by

@@ -333,6 +333,34 @@ def reinforce_scatter(idx, loss_value, B, it_matches, ncell):
     call("mk_reinforce_scatter", ptr(idx), ptr(loss_value), ptr(grads), ptr(grads_b), B, it_matches, S, ncell, stream())
     return grads, grads_b
 
+def train_tail_fwd(X, Y, mask, Rgt, tgt, K0, K1, it_ransac, it_matches, th_soft, loss_type, soft_clip, img_h=720.0):
+    """Forward of the differentiable RANSAC tail (mk_train_tail_fwd): -> (out [nhyp, 4], Rt [nhyp, 12], saved [nhyp, 32])."""
+    X, Y, mask, Rgt, tgt, K0, K1 = _c(X, Y, mask, Rgt, tgt, K0, K1)
+    nsets, S, _ = X.shape
+    nh = nsets * it_ransac
+    dev = X.device
+    out = torch.empty((nh, 4), device=dev, dtype=torch.float32)
+    Rt = torch.empty((nh, 12), device=dev, dtype=torch.float32)
+    saved = torch.zeros((nh, 32), device=dev, dtype=torch.float32)
+    call("mk_train_tail_fwd", ptr(X), ptr(Y), ptr(mask), ptr(Rgt), ptr(tgt), ptr(K0), ptr(K1), nsets, it_ransac, S, it_matches,
+         float(th_soft), int(loss_type), int(soft_clip), float(img_h), ptr(out), ptr(Rt), ptr(saved), stream())
+    return out, Rt, saved
+
+
+def train_tail_bwd(X, Y, mask, Rgt, tgt, K0, K1, it_ransac, it_matches, th_soft, loss_type, soft_clip, Rt, saved, grad_out,
+                   img_h=720.0):
+    """Backward of the same (mk_train_tail_bwd): grad_out [nhyp, 2] = dL/d(loss_value, score) -> (dL/dX, dL/dY) [nsets, S, 3]."""
+    X, Y, mask, Rgt, tgt, K0, K1, grad_out = _c(X, Y, mask, Rgt, tgt, K0, K1, grad_out)
+    nsets, S, _ = X.shape
+    dev = X.device
+    work = torch.empty((nsets * it_ransac, 16), device=dev, dtype=torch.float32)
+    gX, gY = torch.empty_like(X), torch.empty_like(Y)
+    call("mk_train_tail_bwd", ptr(X), ptr(Y), ptr(mask), ptr(Rgt), ptr(tgt), ptr(K0), ptr(K1), nsets, it_ransac, S, it_matches,
+         float(th_soft), int(loss_type), int(soft_clip), float(img_h), ptr(Rt), ptr(saved), ptr(grad_out), ptr(work), ptr(gX),
+         ptr(gY), stream())
+    return gX, gY
+
+
 def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers, invalid=None):
     X, Y, Rh, th, score = _c(X, Y, Rh, th, score)
     k = X.shape[1]

@@ -8,14 +8,15 @@ Where the work goes:
   * NUM_CORR_3d3d-point hypotheses and the <= NUM_REF_STEPS refinement rounds of all B*IT_MATCHES*IT_RANSAC hypotheses
     (:148-184, the no-grad block): `mk_train_ransac_masks`, one wave per hypothesis;
   * the REINFORCE scatter the reference runs as a python loop over B*IT_MATCHES rows (:251-261): `mk_reinforce_scatter`;
-  * the part autograd must see -- back-projection of the sampled keypoints, the final masked Procrustes, soft inlier
-    score, VCRE / pose loss, softmax aggregation (:139-146, :187-246) -- stays in torch on the device, written with the
-    reference's operations so that `avg_loss.backward()` fills outputs['kps0'|'kps1'|'depth0'|'depth1'].grad as the
-    reference's trainer expects (lib/models/MicKey/model.py:101-128).
+  * the differentiable tail -- the final masked Procrustes of every hypothesis, its soft inlier score and its VCRE / pose
+    loss (:187-246) -- is a torch.autograd.Function whose forward AND backward are HIP kernels (`mk_train_tail_fwd` /
+    `mk_train_tail_bwd`: one wave per hypothesis, the 3x3 SVD differentiated in closed form);
+  * what is left to torch: the gather + back-projection of the sampled keypoints (:139-146) and the softmax aggregation over
+    the hypotheses of a set (tiny [B*IT_MATCHES, IT_RANSAC] tensors), so that `avg_loss.backward()` fills
+    outputs['kps0'|'kps1'|'depth0'|'depth1'].grad as the reference's trainer expects (lib/models/MicKey/model.py:101-128).
 
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
 """
-import numpy as np
 import torch
 
 from . import ops
@@ -28,87 +29,28 @@ def backproject_3d(uv, depth, K):
     return depth * (torch.linalg.inv(K) @ torch.cat([uv, ones], -1).transpose(2, 1)).transpose(2, 1)
 
 
-def project_2d(P, K):
-    """reference utils/training_utils.py:24-35."""
-    q = (K @ P.transpose(2, 1)).transpose(2, 1)
-    return (q / (q[:, :, 2:3] + 1e-16))[:, :, :2]
+class _RansacTail(torch.autograd.Function):
+    """reference loss_class.py:187-246 -- the masked Procrustes of every hypothesis, its soft inlier score and its loss -- as
+    two HIP entry points (mk_train_tail_fwd / mk_train_tail_bwd, csrc/mk_train_tail.hip): forward AND backward; the SVD is
+    differentiated in closed form.  Inputs that the reference detaches (mask, ground truth, intrinsics) get no gradient."""
 
+    @staticmethod
+    def forward(ctx, X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft):
+        out, Rt, saved = ops.train_tail_fwd(X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft)
+        ctx.save_for_backward(X, Y, mask, Rgt, tgt, K0, K1, Rt, saved)
+        ctx.cfg = (it_r, it_m, th, loss_type, soft)
+        loss_value, loss_rot, loss_trans, score = (out[:, i].contiguous() for i in range(4))
+        ctx.mark_non_differentiable(loss_rot, loss_trans, Rt, saved)
+        return loss_value, loss_rot, loss_trans, score, Rt, saved
 
-def weighted_procrustes_masked(A, Bp, w, eps=1e-16):
-    """reference loss/solvers.py:13-26,45-52 with use_weights=True, use_mask=True: centroids weighted by w / (sum|w| + eps),
-    covariance by the raw mask, R = V diag(1, 1, det(U V^T)) U^T, t = b_mean - a_mean R^T.  Differentiable."""
-    wn = (w / (w.abs().sum(1, keepdim=True) + eps)).unsqueeze(-1)
-    a_mean = (wn * A).sum(1, keepdim=True)
-    b_mean = (wn * Bp).sum(1, keepdim=True)
-    H = (A - a_mean).transpose(1, 2) @ (w.unsqueeze(-1) * (Bp - b_mean))
-    U, _, V = torch.svd(H)
-    Z = torch.eye(3, device=A.device, dtype=A.dtype).repeat(A.shape[0], 1, 1)
-    Z[:, 2, 2] = torch.sign(torch.linalg.det(U @ V.transpose(1, 2)))
-    R = V @ Z @ U.transpose(1, 2)
-    return R, b_mean - a_mean @ R.transpose(1, 2), H
-
-
-def soft_inlier_counting_3d(X0, X1, R, t, th):
-    """reference utils/training_utils.py:55-61."""
-    d = (((((R @ X0.transpose(2, 1)).transpose(2, 1) + t) - X1) ** 2.0).sum(-1) + 1e-6) ** 0.5
-    return torch.sigmoid((5.0 / th) * (th - d)).sum(-1).view(X0.shape[0], 1)
-
-
-def rot_angle_loss(R, Rgt):
-    """reference loss/loss_utils.py:105-121."""
-    tr = torch.diagonal(R.transpose(1, 2) @ Rgt, dim1=-2, dim2=-1).sum(-1)
-    return torch.acos(torch.clip((tr - 1) / 2, -0.99999, 0.99999)).abs().unsqueeze(-1)
-
-
-def trans_l1_loss(t, tgt):
-    """reference loss/loss_utils.py:95-103."""
-    return (t - tgt).abs().sum(-1)
-
-
-_EYE = {}
-
-
-def eye_grid(device):
-    """The benchmark's 7 x 4 x 7 grid of virtual points (reference lib/benchmarks/reprojection.py:34-58), [196, 3]."""
-    key = str(device)
-    if key not in _EYE:
-        x = (np.arange(7) - 3.0) * 0.3
-        y = (np.arange(4) - 1.5) * 0.3
-        z = np.arange(7).astype(float) * 0.3 + 1.8
-        xx, yy, zz = np.meshgrid(x, y, z)
-        _EYE[key] = torch.from_numpy(np.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)).float().to(device)
-    return _EYE[key]
-
-
-def vcre_loss(R, t, Rgt, tgt, K, H=720):
-    """reference lib/utils/metrics.py:56-80."""
-    M = R.shape[0]
-    E = eye_grid(R.device).unsqueeze(0).expand(M, -1, -1)
-    uv_gt = project_2d(E, K)
-    moved = R @ E.transpose(2, 1) + t.transpose(2, 1)
-    resid = (Rgt.transpose(2, 1) @ moved - Rgt.transpose(2, 1) @ tgt.transpose(2, 1)).transpose(2, 1)
-    uv = project_2d(resid, K)
-    uv_gt, uv = torch.clip(uv_gt, 0, H), torch.clip(uv, 0, H)
-    return ((((uv_gt - uv) ** 2.0).sum(-1) + 1e-6) ** 0.5).mean(-1).view(M, 1)
-
-
-def compute_pose_loss(R, t, Rgt, tgt, K0=None, K1=None, soft_clipping=True):
-    """reference loss/loss_utils.py:27-39."""
-    l_rot, l_tr = rot_angle_loss(R, Rgt), trans_l1_loss(t, tgt)
-    loss = torch.tanh(l_rot / 0.9) + torch.tanh(l_tr / 0.9) if soft_clipping else l_rot + l_tr
-    return loss, l_rot, l_tr
-
-
-def compute_vcre_loss(R, t, Rgt, tgt, K0, K1, soft_clipping=True):
-    """reference loss/loss_utils.py:41-69: VCRE of the pose under K0 and of the inverse pose under K1, averaged."""
-    Ri = R.transpose(2, 1)
-    ti = (-1 * Ri @ t.transpose(2, 1)).transpose(2, 1)
-    Rgi = Rgt.transpose(2, 1)
-    tgi = (-1 * Rgi @ tgt.transpose(2, 1)).transpose(2, 1)
-    loss = (vcre_loss(Ri, ti, Rgi, tgi, K1) + vcre_loss(R, t, Rgt, tgt, K0)) / 2.0
-    if soft_clipping:
-        loss = torch.tanh(loss / 80)
-    return loss, rot_angle_loss(R, Rgt), trans_l1_loss(t, tgt)
+    @staticmethod
+    def backward(ctx, g_loss, g_rot, g_trans, g_score, g_Rt, g_saved):
+        X, Y, mask, Rgt, tgt, K0, K1, Rt, saved = ctx.saved_tensors
+        it_r, it_m, th, loss_type, soft = ctx.cfg
+        zero = torch.zeros((Rt.shape[0],), device=X.device)
+        g = torch.stack([g_loss if g_loss is not None else zero, g_score if g_score is not None else zero], 1).float()
+        gX, gY = ops.train_tail_bwd(X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft, Rt, saved, g)
+        return (gX, gY) + (None,) * 10
 
 
 class MetricPoseLoss(torch.nn.Module):
@@ -121,10 +63,8 @@ class MetricPoseLoss(torch.nn.Module):
         self.loss_type = L["LOSS_FUNCTION"]
         self.soft_clipping = L["SOFT_CLIPPING"]
         if self.loss_type == "POSE_ERR":
-            self.compute_loss = compute_pose_loss
             sub = L["POSE_ERR"]
         elif self.loss_type == "VCRE":
-            self.compute_loss = compute_vcre_loss
             sub = L["VCRE"]
         else:
             raise ValueError("LOSS_CLASS.LOSS_FUNCTION must be 'VCRE' or 'POSE_ERR', got %r" % (self.loss_type,))
@@ -217,21 +157,25 @@ class MetricPoseLoss(torch.nn.Module):
         mask, idx_in, rounds = ops.train_ransac_masks(
             X.detach(), Y.detach(), weights, it_r, float(self.inlier_ref_th), self.num_ref_steps, nc, idx_in=idx_inner,
             seed=self.seed, offset=2 * call + 1, set_base=int(batch.get("pair_base", self._default_pair_base())) * it_m)
-        X_v = X.unsqueeze(1).expand(Ro, it_r, S, 3).reshape(Ri, S, 3)
-        Y_v = Y.unsqueeze(1).expand(Ro, it_r, S, 3).reshape(Ri, S, 3)
-        R, t, H = weighted_procrustes_masked(X_v, Y_v, mask)
-        dbg.update(idx_outer=idx_outer, idx_inner=idx_in, inliers_final=mask, rounds=rounds, R=R.detach(), t=t.detach())
-        if check_rank and int((torch.linalg.matrix_rank(H.detach()) == 1).sum().item()) > 0:
-            print("[ERROR]: Skipping RANSAC iteration due to rank matrix.")
-            return bail()
-        if not bool(torch.isfinite(R).all().item() and torch.isfinite(t).all().item()):
+        # the differentiable tail (reference :187-246): masked Procrustes, soft inlier score and loss of every hypothesis,
+        # forward and backward in HIP; autograd continues from dL/dX, dL/dY into the back-projection above
+        pair_b = lambda v, w: v.float().reshape(B, w).contiguous()  # noqa: E731
+        vcre = self.loss_type == "VCRE"
+        loss_value_k, loss_rot_k, loss_trans_k, score_k, Rt, saved = _RansacTail.apply(
+            X, Y, mask, pair_b(Rgt, 9), pair_b(tgt, 3), pair_b(batch["Kori_color0"], 9) if vcre else None,
+            pair_b(batch["Kori_color1"], 9) if vcre else None, it_r, it_m, float(self.inlier_3d_th), 0 if vcre else 1,
+            bool(self.soft_clipping))
+        R, t = Rt[:, :9].reshape(Ri, 3, 3), Rt[:, 9:].reshape(Ri, 1, 3)
+        dbg.update(idx_outer=idx_outer, idx_inner=idx_in, inliers_final=mask, rounds=rounds, R=R, t=t)
+        if check_rank:
+            # torch.linalg.matrix_rank(H) == 1 (reference :190): singular values above max(S) * 3 * eps(fp32)
+            sv = saved[:, 18:21]
+            if int(((sv > sv[:, :1] * 3 * 1.1920929e-07).sum(1) == 1).sum().item()) > 0:
+                print("[ERROR]: Skipping RANSAC iteration due to rank matrix.")
+                return bail()
+        if not bool(torch.isfinite(Rt).all().item()):
             print("[ERROR]: Skipping RANSAC iteration due to invalid values in R/t.")
             return bail()
-        score_k = soft_inlier_counting_3d(X_v, Y_v, R, t, th=self.inlier_3d_th)
-        pair_of_hyp = torch.arange(B, device=dev).repeat_interleave(it_m * it_r)
-        loss_value_k, loss_rot_k, loss_trans_k = self.compute_loss(
-            R, t, Rgt.float()[pair_of_hyp], tgt.float()[pair_of_hyp], batch["Kori_color0"].float()[pair_of_hyp],
-            batch["Kori_color1"].float()[pair_of_hyp], soft_clipping=self.soft_clipping)
         loss_value_k, loss_rot_k, loss_trans_k, score_k = (v.reshape(Ro, it_r) for v in (loss_value_k, loss_rot_k, loss_trans_k, score_k))
         sm = torch.softmax(score_k / self.score_temperature, -1)
         loss_rot = (loss_rot_k * sm).sum(-1).unsqueeze(-1)

@@ -121,6 +121,64 @@ def test_reinforce_scatter_bit_exact():
     assert float(want_b.max()) >= 3   # cells drawn by several rows are present
 
 
+@pytest.mark.parametrize("kind,soft", [("VCRE", True), ("VCRE", False), ("POSE_ERR", True), ("POSE_ERR", False)])
+def test_native_tail_forward_and_gradients_vs_oracle_autograd(kind, soft):
+    """mk_train_tail_fwd / mk_train_tail_bwd (one wave per hypothesis: masked Procrustes with a closed-form SVD adjoint, soft
+    inlier score, VCRE / pose loss) against the oracle's restatement of loss_class.py:187-246 run through torch autograd in
+    fp64 on the CPU: per-hypothesis losses and scores, and dL/dX, dL/dY for random upstream gradients."""
+    from mickey_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, it_m, it_r, S = 2, 3, 5, 200
+    nsets, nh = B * it_m, B * it_m * it_r
+    Rg = torch.stack([TO._rodrigues(torch.tensor([0.1, -0.2, 0.05]) * (b + 1)) for b in range(B)])
+    tg = torch.tensor([[[0.3, -0.1, 0.2]], [[-0.2, 0.25, 0.1]]])
+    X = torch.randn((nsets, S, 3), generator=g) * torch.tensor([1.5, 1.0, 0.7]) + torch.tensor([0.2, -0.1, 4.0])
+    pair = torch.arange(B).repeat_interleave(it_m)
+    Y = (Rg[pair] @ X.transpose(1, 2)).transpose(1, 2) + tg[pair] + 0.05 * torch.randn((nsets, S, 3), generator=g)
+    Y[:, ::3] += 0.6 * torch.randn((nsets, (S + 2) // 3, 3), generator=g)          # a third of the matches are outliers
+    mask = (torch.rand((nh, S), generator=g) < 0.15).float()
+    mask[:, :8] = 1.0                                                               # never fewer than 8 matches
+    mask[3] = 0.0
+    mask[3, 5:13] = 1.0                                                             # a minimal hypothesis
+    K0 = torch.tensor([[[590.0, 0, 270.0], [0, 590.0, 360.0], [0, 0, 1.0]]]).repeat(B, 1, 1)
+    K1 = torch.tensor([[[585.0, 0, 268.0], [0, 588.0, 355.0], [0, 0, 1.0]]]).repeat(B, 1, 1)
+    th = 0.5
+    gl, gs = torch.randn((nh,), generator=g), 0.1 * torch.randn((nh,), generator=g)
+    # oracle, fp64 autograd (torch.eye / the eye grid of the oracle follow the default dtype / are cast for the occasion)
+    eye0 = TO.eye_grid
+    torch.set_default_dtype(torch.float64)
+    TO.eye_grid = lambda: eye0().double()
+    try:
+        Xd, Yd = X.double().requires_grad_(), Y.double().requires_grad_()
+        Xv = Xd.unsqueeze(1).expand(nsets, it_r, S, 3).reshape(nh, S, 3)
+        Yv = Yd.unsqueeze(1).expand(nsets, it_r, S, 3).reshape(nh, S, 3)
+        R, t, _ = mo.kabsch(Xv, Yv, mask.double(), masked=True)
+        score = mo.soft_inliers(Xv, Yv, R, t, th).reshape(nh)
+        ph = torch.arange(B).repeat_interleave(it_m * it_r)
+        lv, lr, lt = TO.pose_loss(kind, R, t, Rg.double()[ph], tg.double()[ph], K0.double()[ph], K1.double()[ph], soft)
+        ((lv.reshape(nh) * gl.double()).sum() + (score * gs.double()).sum()).backward()
+        R, t, lv, lr, lt, score = (v.detach().float() for v in (R, t, lv, lr, lt, score))
+        gXd, gYd = Xd.grad.float(), Yd.grad.float()
+    finally:
+        torch.set_default_dtype(torch.float32)
+        TO.eye_grid = eye0
+    # native
+    dv = lambda v: v.to(DEV)  # noqa: E731
+    lt_code = 0 if kind == "VCRE" else 1
+    out, Rt, saved = ops.train_tail_fwd(dv(X), dv(Y), dv(mask), dv(Rg.reshape(B, 9)), dv(tg.reshape(B, 3)), dv(K0.reshape(B, 9)),
+                                        dv(K1.reshape(B, 9)), it_r, it_m, th, lt_code, soft)
+    gX, gY = ops.train_tail_bwd(dv(X), dv(Y), dv(mask), dv(Rg.reshape(B, 9)), dv(tg.reshape(B, 3)), dv(K0.reshape(B, 9)),
+                                dv(K1.reshape(B, 9)), it_r, it_m, th, lt_code, soft, Rt, saved, dv(torch.stack([gl, gs], 1)))
+    errs = {"R": rel(Rt[:, :9].cpu(), R.reshape(nh, 9)), "t": rel(Rt[:, 9:].cpu(), t.reshape(nh, 3)),
+            "loss": rel(out[:, 0].cpu(), lv.reshape(nh)), "rot": rel(out[:, 1].cpu(), lr.reshape(nh)),
+            "trans": rel(out[:, 2].cpu(), lt.reshape(nh)), "score": rel(out[:, 3].cpu(), score),
+            "gX": rel(gX.cpu(), gXd), "gY": rel(gY.cpu(), gYd)}
+    print(kind, soft, {k: "%.2e" % v for k, v in errs.items()})
+    for k, tol in (("R", 2e-6), ("t", 2e-6), ("loss", 2e-5), ("rot", 2e-4), ("trans", 2e-6), ("score", 2e-6), ("gX", 2e-4), ("gY", 2e-4)):
+        assert errs[k] < tol, (k, errs[k])
+    assert bool(torch.isfinite(gX).all() and torch.isfinite(gY).all())
+
+
 @pytest.mark.parametrize("name", ["small", "pose_err", "default"])
 def test_metric_pose_loss_vs_reference_golden(name):
     """the drop-in class with the reference's draws replayed: losses, REINFORCE gradients and the keypoint / depth

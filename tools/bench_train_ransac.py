@@ -68,10 +68,19 @@ def main():
           lambda: ops.train_ransac_masks(X, Y, w, 20, 0.15, 4, 8, seed=1, offset=1))
     lv = torch.rand(B * 20, device=dev)
     timed("REINFORCE scatter (mk_reinforce_scatter)", lambda: ops.reinforce_scatter(idx, lv, B, 20, n * n))
+    mask, _, _ = ops.train_ransac_masks(X, Y, w, 20, 0.15, 4, 8, seed=1, offset=1)
+    T = b["T_0to1"].float()
+    Rg, tg = T[:, :3, :3].reshape(B, 9).contiguous(), T[:, :3, 3].reshape(B, 3).contiguous()
+    K0, K1 = b["Kori_color0"].float().reshape(B, 9).contiguous(), b["Kori_color1"].float().reshape(B, 9).contiguous()
+    o, Rt, saved = timed("differentiable tail, forward (mk_train_tail_fwd: Procrustes + SVD + score + VCRE of %d hypotheses)" % (B * 400),
+                         lambda: ops.train_tail_fwd(X, Y, mask, Rg, tg, K0, K1, 20, 20, 0.5, 0, True))
+    gg = torch.rand((B * 400, 2), device=dev)
+    timed("differentiable tail, backward (mk_train_tail_bwd)",
+          lambda: ops.train_tail_bwd(X, Y, mask, Rg, tg, K0, K1, 20, 20, 0.5, 0, True, Rt, saved, gg))
     out = {"what": "MetricPoseLoss forward + backward (training-time RANSAC, SURVEY row N3)", "pairs": B, "keypoints": n,
            "ms_per_step": ms, "pairs_per_s": B / ms * 1e3, "avg_loss": float(avg.detach()), "valid": nvalid,
            "hip_stage_ms": {k: round(v, 3) for k, v in stages.items()},
-           "torch_autograd_tail_ms": round(ms - sum(stages.values()), 3)}
+           "torch_remainder_ms (gather + back-projection + softmax aggregation, forward and backward, host launches)": round(ms - sum(stages.values()), 3)}
     if args.cpu_pairs > 0:
         cb = TO.synthetic_batch(args.cpu_pairs, args.n, seed=1, noise=0.12)
         g = torch.Generator().manual_seed(0)
