@@ -14,6 +14,7 @@ run attn1 ATTN_MODE=1 pmc_attn.py
 run attn2 ATTN_MODE=2 pmc_attn.py
 run attn3 ATTN_MODE=3 pmc_attn.py
 run gemm7 GEMM_MODE=7 pmc_gemm.py
+run gemm_hipblaslt GEMM_MODE=-1 pmc_gemm.py
 python - <<'PY'
 import collections, csv, glob, json, os
 out = {}
@@ -35,7 +36,8 @@ for d in sorted(glob.glob("/tmp/pc_*")):
     rows = []
     for did, c in acc.items():
         name, ns = dur.get(did, ("?", 0.0))
-        if ("attn" in name or "gemm_pp64" in name) and ns > 0 and "GRBM_GUI_ACTIVE" in c:
+        hot = "attn" in name or "gemm_pp64" in name or (tag == "gemm_hipblaslt" and ("Cijk" in name or "gemm" in name.lower()))
+        if hot and ns > 0 and "GRBM_GUI_ACTIVE" in c:
             rows.append((ns, c["GRBM_GUI_ACTIVE"] / 8.0, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0))
     rows = rows[len(rows) // 3:]   # drop the first (cold-clock) third
     if rows:
