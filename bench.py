@@ -259,6 +259,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the vit_small and config5 legs")
+    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, vit_small, config5)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step sustained leg")
     ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no sustained / PCIe / "
                                                          "single-pair / CPU legs (profiling passes)")
@@ -544,6 +545,8 @@ def main(argv=None):
     def leg(name, what, dtype, steps, warmup, batch_pairs=None, hw=(H, W), dominant="encoder_gemm", **mk):
         """One more full timed run (same measure(): barrier-free at N = 1, synchronize on both sides) of another
         precision / configuration, with its own per-stage roofline list."""
+        if args.legs is not None and name not in args.legs.split(","):
+            return
         bp = batch_pairs or B
         m, _, _ = make_model(dtype, **mk)
         d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=bp, H=hw[0], W=hw[1], seed=1234).items()}
@@ -570,8 +573,9 @@ def main(argv=None):
             "(MICKEY.DINOV2.FLOAT16), heads in fp16 too", "fp16", args.steps, args.warmup)
         leg("ref_split", "fp16 encoder + fp32 heads (fp32 MFMA): the reference's exact precision split "
             "(mickey_extractor.py:49-56)", "fp16", max(3, args.steps // 4), 1, heads_fp32=True)
-        out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
-                      "note": "= legs.fp16 (kept for readers of the round-2 line)"}
+        if "fp16" in out.get("legs", {}):
+            out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
+                          "note": "= legs.fp16 (kept for readers of the round-2 line)"}
     if single and not args.no_legs:
         leg("vit_small", "DINOv2 ViT-S/14 encoder (the size north_star names; 305 GFLOP per pair, attention 46 %% of it) "
             "+ the same heads / matcher / solver, %d pairs of 540x720" % B, args.dtype, max(5, args.steps // 2), 2,

@@ -44,12 +44,6 @@ __device__ __forceinline__ f32x16 corr_tile(const float* sA, const float* sB, in
   return acc;
 }
 
-__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {   // natural-log domain (Sinkhorn)
-  const float M = fmaxf(m, m2);
-  s = s * expf(m - M) + s2 * expf(m2 - M);
-  m = M;
-}
-
 // ---- dual softmax: register-resident correlation ---------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32 takes ONE float per lane per operand (lane l: row/column l & 31, k = 2 kk + (l >> 5)), so a
 // wave keeps the descriptors of its 32 rows in 64 VGPRs for its whole life and streams 32-column tiles of the other
@@ -273,10 +267,19 @@ __global__ __launch_bounds__(256) void dual_softmax_apply_kernel(const float* vb
 }
 
 // ---- sinkhorn ---------------------------------------------------------------------------------------
-// Z[(n0+1) x (n1+1)] = couplings (S / sqrt(C) with alpha on the last row / column / corner)
+// log_optimal_transport (feature_matcher.py:89-123) in the log2 domain: Z2 = Z log2(e), u2 = u log2(e), v2 = v log2(e), so that
+// every exponential / logarithm is one v_exp_f32 / v_log_f32.  The bound is HBM: 2 passes over the (n0+1) x (n1+1) coupling
+// matrix per iteration (20 LSE passes + 1 write = 301 MB per pair at 540x720).  Rows are padded to a multiple of 4
+// floats (ldz; the pad holds -1e30 = contributes 0) so that both passes move 16 bytes per lane; the running maximum of an online
+// log-sum-exp is updated per BLOCK of values (4 per lane in the row pass, 8 rows in the column pass): 1.25 / 1.125 exponentials
+// per element instead of 2; the column pass is split over 256-row chunks (2900 workgroups at 1280x720 instead of 150) whose
+// partial (max, sum) pairs a small kernel merges.
+constexpr int SK_RCH = 256;   // rows per chunk of the column pass
+
+// Z2[(n0+1) x ldz] = couplings * log2(e) (S / sqrt(C), alpha on the last row / column / corner, -1e30 in the row pad)
 __global__ __launch_bounds__(256) void couplings_kernel(const float* __restrict__ dsc0, const float* __restrict__ dsc1,
-                                                        float scale, float alpha, float* __restrict__ Z, int C, int n0,
-                                                        int n1) {
+                                                        float scale2, float alpha2, float* __restrict__ Z, int C, int n0,
+                                                        int n1, int ldz) {
   __shared__ __attribute__((aligned(16))) float sA[CMAX * MT];
   __shared__ __attribute__((aligned(16))) float sB[CMAX * MT];
   const int b = blockIdx.z, i0 = blockIdx.y * MT, j0 = blockIdx.x * MT;
@@ -287,76 +290,120 @@ __global__ __launch_bounds__(256) void couplings_kernel(const float* __restrict_
   __syncthreads();
   const f32x16 acc = corr_tile(sA, sB, C, wi, wj, lane);
   const int jx = j0 + wj * 32 + l31;
-  if (jx > n1) return;
-  float* Zb = Z + (long long)b * (n0 + 1) * (n1 + 1);
+  if (jx >= ldz) return;
+  float* Zb = Z + (long long)b * (n0 + 1) * ldz;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     if (i > n0) continue;
-    Zb[(long long)i * (n1 + 1) + jx] = (i == n0 || jx == n1) ? alpha : acc[r] * scale;
+    Zb[(long long)i * ldz + jx] = jx > n1 ? -1e30f : ((i == n0 || jx == n1) ? alpha2 : acc[r] * scale2);
   }
 }
 
-// u[i] = log_mu[i] - LSE_j(Z[i][j] + v[j]); one wave per row
+// u2[i] = log_mu2[i] - LSE2_j(Z2[i][j] + v2[j]); one wave per row, 16 bytes per lane
 __global__ __launch_bounds__(256) void sink_row_kernel(const float* __restrict__ Z, const float* __restrict__ v,
-                                                       float* __restrict__ u, int n0, int n1, float norm, float log_last) {
+                                                       float* __restrict__ u, int n0, int ldz, int ldu, float norm2, float last2) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (i > n0) return;
-  const float* z = Z + ((long long)b * (n0 + 1) + i) * (n1 + 1);
-  const float* vb = v + (long long)b * (n1 + 1);
+  const f32x4* z = (const f32x4*)(Z + ((long long)b * (n0 + 1) + i) * ldz);
+  const f32x4* vb = (const f32x4*)(v + (long long)b * ldz);
   float m = -1e30f, s = 0.f;
-  for (int j = lane; j <= n1; j += 64) {
-    const float x = z[j] + vb[j];
-    const float M = fmaxf(m, x);
-    s = s * expf(m - M) + expf(x - M);
+  for (int j4 = lane; j4 < (ldz >> 2); j4 += 64) {
+    const f32x4 x = __builtin_nontemporal_load(z + j4) + vb[j4];
+    const float M = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), m);
+    s = s * __builtin_amdgcn_exp2f(m - M) + ((__builtin_amdgcn_exp2f(x[0] - M) + __builtin_amdgcn_exp2f(x[1] - M)) +
+                                             (__builtin_amdgcn_exp2f(x[2] - M) + __builtin_amdgcn_exp2f(x[3] - M)));
     m = M;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-    lse_merge(m, s, m2, s2);
+    lse2_merge(m, s, m2, s2);
   }
-  if (lane == 0) u[(long long)b * (n0 + 1) + i] = (i == n0 ? log_last : norm) - (m + logf(s));
+  if (lane == 0) u[(long long)b * ldu + i] = (i == n0 ? last2 : norm2) - (m + __builtin_amdgcn_logf(s));
 }
 
-// v[j] = log_nu[j] - LSE_i(Z[i][j] + u[i]); block = 64 columns x 4 row groups
-__global__ __launch_bounds__(256) void sink_col_kernel(const float* __restrict__ Z, const float* __restrict__ u,
-                                                       float* __restrict__ v, int n0, int n1, float norm, float log_last) {
-  __shared__ float sm[4][64], ss[4][64];
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6, b = blockIdx.y;
-  const int j = blockIdx.x * 64 + col;
-  const float* Zb = Z + (long long)b * (n0 + 1) * (n1 + 1);
-  const float* ub = u + (long long)b * (n0 + 1);
-  float m = -1e30f, s = 0.f;
-  if (j <= n1) {
-    for (int i = rg; i <= n0; i += 4) {
-      const float x = Zb[(long long)i * (n1 + 1) + j] + ub[i];
-      const float M = fmaxf(m, x);
-      s = s * expf(m - M) + expf(x - M);
-      m = M;
-    }
-  }
-  sm[rg][col] = m;
-  ss[rg][col] = s;
-  __syncthreads();
-  if (rg == 0 && j <= n1) {
+// column pass, part 1: (max, sum) of 2^(Z2[i][j] + u2[i]) over the rows of one 256-row chunk for 256 columns; a wave takes 64 of
+// the rows, 8 at a time (one running-maximum update per 8 values of a column), a lane 4 adjacent columns
+__global__ __launch_bounds__(256) void sink_col_part_kernel(const float* __restrict__ Z, const float* __restrict__ u,
+                                                            float2* __restrict__ part, int n0, int ldz, int ldu, int nrc) {
+  __shared__ f32x4 sm[4][64], ss[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.z, rc = blockIdx.y;
+  const int j = (blockIdx.x * 64 + lane) * 4;
+  const bool jok = j < ldz;
+  const float* Zb = Z + (long long)b * (n0 + 1) * ldz + (jok ? j : 0);
+  const float* ub = u + (long long)b * ldu;
+  f32x4 m = f32x4{-1e30f, -1e30f, -1e30f, -1e30f}, sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r0 = rc * SK_RCH + wave * 64;
+  for (int r = r0; r < r0 + 64 && r <= n0; r += 8) {
+    f32x4 x[8];
 #pragma unroll
-    for (int g = 1; g < 4; ++g) lse_merge(m, s, sm[g][col], ss[g][col]);
-    v[(long long)b * (n1 + 1) + j] = (j == n1 ? log_last : norm) - (m + logf(s));
+    for (int k = 0; k < 8; ++k) {
+      const int i = r + k;
+      // rows past the end repeat the last row with -inf added: no branch in the loads
+      const int ic = i <= n0 ? i : n0;
+      const float ui = i <= n0 ? ub[ic] : -1e30f;
+      x[k] = __builtin_nontemporal_load((const f32x4*)(Zb + (long long)ic * ldz)) + ui;
+    }
+    f32x4 M = m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) M[e] = fmaxf(M[e], x[k][e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += __builtin_amdgcn_exp2f(x[k][e] - M[e]);
+      sacc[e] = sacc[e] * __builtin_amdgcn_exp2f(m[e] - M[e]) + t;
+    }
+    m = M;
   }
+  sm[wave][lane] = m;
+  ss[wave][lane] = sacc;
+  __syncthreads();
+  if (wave == 0 && jok) {
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      const f32x4 m2 = sm[g][lane], s2 = ss[g][lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float me = m[e], se = sacc[e];
+        lse2_merge(me, se, m2[e], s2[e]);
+        m[e] = me;
+        sacc[e] = se;
+      }
+    }
+    float2* o = part + ((long long)b * nrc + rc) * ldz + j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = make_float2(m[e], sacc[e]);
+  }
+}
+
+// column pass, part 2: v2[j] = log_nu2[j] - log2 of the merged chunk partials
+__global__ __launch_bounds__(256) void sink_col_fin_kernel(const float2* __restrict__ part, float* __restrict__ v, int n1, int ldz,
+                                                           int nrc, float norm2, float last2) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ldz) return;
+  float m = -1e30f, s = 0.f;
+  for (int rc = 0; rc < nrc; ++rc) {
+    const float2 p = part[((long long)b * nrc + rc) * ldz + j];
+    lse2_merge(m, s, p.x, p.y);
+  }
+  v[(long long)b * ldz + j] = j > n1 ? 0.f : (j == n1 ? last2 : norm2) - (m + __builtin_amdgcn_logf(s));
 }
 
 __global__ __launch_bounds__(256) void sink_final_kernel(const float* __restrict__ Z, const float* __restrict__ u,
-                                                         const float* __restrict__ v, float norm,
+                                                         const float* __restrict__ v, float norm2,
                                                          const float* __restrict__ scr0, const float* __restrict__ scr1,
                                                          float* __restrict__ out, float* __restrict__ kp,
-                                                         float* __restrict__ fin, int n0, int n1) {
+                                                         float* __restrict__ fin, int n0, int n1, int ldz, int ldu) {
   const int b = blockIdx.z, i = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n1) return;
-  const float z = Z[((long long)b * (n0 + 1) + i) * (n1 + 1) + j];
-  const float pr = expf(z + u[(long long)b * (n0 + 1) + i] + v[(long long)b * (n1 + 1) + j] - norm);
+  const float z = Z[((long long)b * (n0 + 1) + i) * ldz + j];
+  const float pr = __builtin_amdgcn_exp2f(z + u[(long long)b * ldu + i] + v[(long long)b * ldz + j] - norm2);
   const long long o = ((long long)b * n0 + i) * n1 + j;
   if (out) out[o] = pr;
   if (scr0) {
@@ -527,8 +574,14 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
   return MK_OK;
 }
 
+static inline int sk_ldz(int n1) { return (n1 + 1 + 3) & ~3; }
+static inline int sk_ldu(int n0) { return (n0 + 1 + 3) & ~3; }
+static inline int sk_nrc(int n0) { return (n0 + 1 + SK_RCH - 1) / SK_RCH; }
+
 long long mk_sinkhorn_work_floats(int B, int n0, int n1) {
-  return (long long)B * ((long long)(n0 + 1) * (n1 + 1) + (n0 + 1) + (n1 + 1));
+  // Z2 (rows padded to 16 bytes) + u2 + v2 + the column pass' chunk partials (max, sum)
+  const long long ldz = sk_ldz(n1);
+  return (long long)B * ((long long)(n0 + 1) * ldz + sk_ldu(n0) + ldz + 2LL * sk_nrc(n0) * ldz);
 }
 
 int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float alpha, int iters, float* scores,
@@ -536,26 +589,31 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const f
   MK_CHECK_ARG(dsc0 && dsc1 && work && (scores || final_scores), "mk_sinkhorn: null pointer");
   MK_CHECK_ARG((scr0 && scr1) || (!kp_scores && !final_scores), "mk_sinkhorn: kp/final scores need scr0 and scr1");
   MK_CHECK_ARG(B > 0 && n0 > 0 && n1 > 0 && C > 0 && C <= CMAX && C % 2 == 0 && iters >= 0, "mk_sinkhorn: bad args");
+  MK_CHECK_ARG(((uintptr_t)work & 15) == 0, "mk_sinkhorn: work must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  const int ldz = sk_ldz(n1), ldu = sk_ldu(n0), nrc = sk_nrc(n0);
   float* Z = work;
-  float* u = Z + (long long)B * (n0 + 1) * (n1 + 1);
-  float* v = u + (long long)B * (n0 + 1);
-  // constants of log_optimal_transport (feature_matcher.py:116-118)
+  float* u = Z + (long long)B * (n0 + 1) * ldz;
+  float* v = u + (long long)B * ldu;
+  float2* part = (float2*)(v + (long long)B * ldz);
+  // constants of log_optimal_transport (feature_matcher.py:116-118), times log2(e)
+  const float LOG2E = 1.4426950408889634f;
   const float norm = -logf((float)n0 + (float)n1);
-  const float log_mu_last = logf((float)n1) + norm, log_nu_last = logf((float)n0) + norm;
-  hipLaunchKernelGGL(couplings_kernel, dim3((n1 + 1 + MT - 1) / MT, (n0 + 1 + MT - 1) / MT, B), dim3(256), 0, st, dsc0, dsc1,
-                     1.0f / sqrtf((float)C), alpha, Z, C, n0, n1);
+  const float norm2 = norm * LOG2E, mu_last2 = (logf((float)n1) + norm) * LOG2E, nu_last2 = (logf((float)n0) + norm) * LOG2E;
+  hipLaunchKernelGGL(couplings_kernel, dim3((ldz + MT - 1) / MT, (n0 + 1 + MT - 1) / MT, B), dim3(256), 0, st, dsc0, dsc1,
+                     LOG2E / sqrtf((float)C), alpha * LOG2E, Z, C, n0, n1, ldz);
   MK_CHECK_LAUNCH();
-  const long long nuv = (long long)B * (n0 + n1 + 2);
+  const long long nuv = (long long)B * (ldu + ldz);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((nuv + 255) / 256)), dim3(256), 0, st, u, 0.f, nuv);
   MK_CHECK_LAUNCH();
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(sink_row_kernel, dim3((n0 + 1 + 3) / 4, B), dim3(256), 0, st, Z, v, u, n0, n1, norm, log_mu_last);
-    hipLaunchKernelGGL(sink_col_kernel, dim3((n1 + 1 + 63) / 64, B), dim3(256), 0, st, Z, u, v, n0, n1, norm, log_nu_last);
+    hipLaunchKernelGGL(sink_row_kernel, dim3((n0 + 1 + 3) / 4, B), dim3(256), 0, st, Z, v, u, n0, ldz, ldu, norm2, mu_last2);
+    hipLaunchKernelGGL(sink_col_part_kernel, dim3((ldz / 4 + 63) / 64, nrc, B), dim3(256), 0, st, Z, u, part, n0, ldz, ldu, nrc);
+    hipLaunchKernelGGL(sink_col_fin_kernel, dim3((ldz + 255) / 256, B), dim3(256), 0, st, part, v, n1, ldz, nrc, norm2, nu_last2);
   }
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, Z, u, v, norm, scr0, scr1, scores, kp_scores,
-                     final_scores, n0, n1);
+  hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, Z, u, v, norm2, scr0, scr1, scores, kp_scores,
+                     final_scores, n0, n1, ldz, ldu);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

