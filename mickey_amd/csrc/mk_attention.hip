@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 
 // Production kernel (mode 9 / automatic): QB sub-blocks of 32 queries per wave, the lean softmax of attn_fwd_lean_kernel with
 // the row sums on the VALU.  What decides between variants on this part is ENERGY per tile, not cycles: the chip runs every
-// attention kernel (and the GEMM) at its power limit -- profiles/r03_pmc_clock_attention_gemm.json: variants that need fewer
+// attention kernel (and the GEMM) at its power limit -- profiles/r03_pmc_clock_attention_variants.json: variants that need fewer
 // cycles run at a lower clock and finish at the same wall time -- so the kernel that issues the least work wins:
 //   * no subtraction of the running maximum (folded into the MFMA accumulator init), no per-tile rescale of O (re-base only
 //     when a tile exceeds the maximum by 2^8), 16 MFMAs per 32 x 64 tile (the matrix-pipe row sums of the lean kernel were a

@@ -11,12 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 KEYS = ("kps0", "kps1", "depth_kp0", "depth_kp1", "scr0", "scr1", "dsc0", "dsc1", "scores", "kp_scores", "final_scores")
-# rel-Frobenius bounds vs the fp32 reference.  16-bit operands (bf16 has 8 mantissa bits, fp16 11): about 2x what is
-# measured on MI355X (bf16: kps 3e-5, depth 1.9e-3, scr 8e-3, dsc 6.9e-3, scores 8.3e-3, final_scores 1.2e-2; fp16: dsc 8e-4,
-# scores 7e-4 -- the reference's OWN fp16 mode sits at dsc 1.15e-3, scores 1.1e-3: tests/golden/noise_floor_fp16.npz), so a
-# real regression does not fit under them.  fp32 (the exact parity mode, fp32-input MFMA): 1e-4, SURVEY.md 8(c) row 1.
+# rel-Frobenius bounds vs the fp32 reference.  bf16 (8 mantissa bits): 1.5x the LARGER of what round 3 measures on MI355X at
+# 182x196 against the reference golden / at 720x540 against the oracle (kps 4.8e-5 / 1.5e-5, depth 1.9e-3 / 2.0e-3, scr 7.7e-3 /
+# 7.2e-3, dsc 6.7e-3 / 6.9e-3, scores 5.8e-3 / 1.07e-2, kp_scores 1.08e-2 / 1.01e-2, final_scores 1.18e-2 / 1.11e-2), with no
+# further allowance at full size.  fp16 (11 bits): ~2x measured (kps 3e-6, depth 2.8e-4, scr 8.4e-4, dsc 7.9e-4, scores 1.0e-3,
+# final_scores 1.3e-3) -- every fp16 figure lies INSIDE the floor of the reference's OWN fp16 mode (fp16 encoder + fp32 heads:
+# kps 9.1e-6, depth 3.6e-4, scr 1.36e-3, dsc 1.15e-3, scores 1.08e-3, tests/golden/noise_floor_fp16.npz) although the heads run
+# in fp16 here too.  fp32 (the exact parity mode, fp32-input MFMA): 1e-4, SURVEY.md 8(c) row 1.
 TOL = {
-    torch.bfloat16: dict(kps=8e-5, depth=4e-3, scr=1.6e-2, dsc=1.4e-2, scores=1.7e-2, kp_scores=3e-2, final_scores=2.5e-2),
+    torch.bfloat16: dict(kps=8e-5, depth=3e-3, scr=1.16e-2, dsc=1.03e-2, scores=1.6e-2, kp_scores=1.62e-2, final_scores=1.77e-2),
     torch.float16: dict(kps=5e-5, depth=1.5e-3, scr=3e-3, dsc=2e-3, scores=2e-3, kp_scores=6e-3, final_scores=4e-3),
     torch.float32: dict(kps=1e-4, depth=1e-4, scr=1e-4, dsc=1e-4, scores=1e-4, kp_scores=1e-4, final_scores=1e-4),
 }
@@ -140,7 +143,7 @@ def test_full_size_pair_vs_oracle(cfg, dtype):
     print("720x540", dtype, {k: "%.2e" % v for k, v in errs.items()})
     for k in KEYS:
         base = k.rstrip("01").replace("depth_kp", "depth")
-        assert errs[k] < (1.0 if dtype == "fp32" else 1.5) * tol[base], (k, errs[k])
+        assert errs[k] < tol[base], (k, errs[k])
     assert data["scores"].shape == (1, 1938, 1938)
     # row arg-max of the score matrix: identical wherever the oracle's top-2 gap exceeds the noise floor
     top2 = odata["scores"].topk(2, dim=2).values
