@@ -124,7 +124,7 @@ class StageProfiler:
         timed("flash_attn", "attention", lambda q, k, vt, out, nimg, heads, ntok, pad: 4.0 * nimg * heads * ntok * ntok * 64)
         # implicit-GEMM 3x3 conv: 2 * M * Cout * (9 C1 + C2) per group
         timed("conv3x3", "conv_gemm",
-              lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, zp, act=0, in2=None, C2=0, **k:
+              lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, act=0, in2=None, C2=0, **k:
               2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
         # the head linears (K = 128..256, fp32 qkv outputs) are write-bound: 1 flop per 3 bytes; priced against HBM
         timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:

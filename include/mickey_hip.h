@@ -137,10 +137,13 @@ int mk_gemm_qkv_ln(const void* A, int lda, const void* W, int ldw, const float* 
  * r % (rows_per_img - skip)  (skip = 1 drops the CLS token, dinov2.py:233).  out lp or fp32.
  * If resid != NULL (fp32 [rows_out, ldr]): resid += LN(x) and `out` receives the updated resid
  * (transformer_utils.py:64-66).  wgroup_rows > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use
- * w + g*D, b + g*D (the four heads normalised in one launch). */
+ * w + g*D, b + g*D (the four heads normalised in one launch).
+ * bord_h > 0: `out` is a stack of BORDERED feature maps (below, mk_bordered_rows) of bord_m = nimg * bord_h * bord_w pixels
+ * each: output row r goes to row (r / bord_m) * mk_bordered_rows(nimg, bord_h, bord_w) + bordered(r % bord_m).  The
+ * border rows are not written.  bord_h = 0: dense rows. */
 int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
-                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int dtype,
-                 mk_stream_t stream);
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
+                 int bord_w, int bord_m, int dtype, mk_stream_t stream);
 
 /* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
  * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
@@ -152,17 +155,27 @@ int mk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* out, i
  * Heads (reference lib/models/MicKey/modules/mickey_extractor.py:67-251)
  * ---------------------------------------------------------------------------------------------- */
 
-/* 3x3 conv, pad 1, as implicit GEMM over NHWC lp activations, BatchNorm folded into W/bias by the
+/* BORDERED feature map: the layout of every activation a 3x3 convolution reads.  Pixel (b, y, x) of a [nimg, H, Wd]
+ * grid is row ((b (H+1) + y + 1)(Wd+1) + x + 1) of a [mk_bordered_rows(nimg, H, Wd), C] matrix; all other rows are the
+ * zero padding of nn.Conv2d(padding=1) (one shared column between grid rows, one shared grid row between images) and
+ * must be zero -- allocate the buffer zeroed once; no kernel of this library ever writes them.  Every 3x3 tap of every
+ * pixel is then the same row shift dy (Wd+1) + dx: the implicit GEMM addresses its A operand like a dense matrix (one
+ * scalar-addressed LDS-DMA instruction per 8 rows; per-lane tap / border arithmetic cost the round-2 kernel 8 %). */
+long long mk_bordered_rows(int nimg, int H, int Wd);
+
+/* 3x3 conv, pad 1, as implicit GEMM over bordered NHWC lp activations, BatchNorm folded into W/bias by the
  * caller (utils/extractor_utils.py:28-35):
  *   out[g][pix, co] = act( sum_{tap,ci} W[g][co, tap*C1+ci] * in1[g][pix+tap, ci]
  *                        + sum_{ci} W[g][co, 9*C1+ci] * in2[g][pix, ci]      (1x1 shortcut, optional)
  *                        + bias[g][co] + resid[g][pix, co] (identity shortcut, optional) )
- * tap = ky*3+kx.  `zero_page`: >= 128 zero bytes in device memory (source of out-of-image taps).
+ * tap = ky*3+kx.  in1, in2, resid: bordered feature maps (resid [.., Cout]).  out_kind: MK_CONV_OUT_DENSE = lp rows
+ * [nimg*H*Wd, Cout]; MK_CONV_OUT_BORDERED = lp, bordered (the next conv's input); MK_CONV_OUT_F32 = fp32 dense rows.
  * C1, C2 % 64 == 0; Cout % 4 == 0.  Strides are element strides per group (0 = shared input). */
+enum { MK_CONV_OUT_DENSE = 0, MK_CONV_OUT_BORDERED = 1, MK_CONV_OUT_F32 = 2 };
 int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, long long stride_in2, int C2, const void* W,
-               int ldw, long long strideW, const float* bias, long long strideBias, const void* resid, void* out, int Cout,
-               long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_is_f32, const void* zero_page,
-               int dtype, mk_stream_t stream);
+               int ldw, long long strideW, const float* bias, long long strideBias, const void* resid, long long strideResid,
+               void* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_kind, int dtype,
+               mk_stream_t stream);
 
 /* Start of Transformer_self_att (att_layers/transformer.py:92-95): xs = x + pe (fp32 stream) and an
  * lp copy into columns [0,C) of a [rows, ld_cat] buffer.  x lp [G][rows, C]; pe fp32 [npix, C] or NULL. */

@@ -34,9 +34,10 @@ SIGNATURES = {
     "mk_gemm_qkv_ln": ("i", "pipipppfppppiiiifip"),
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
-    "mk_layernorm": ("i", "pippfpiipiiiiiiip"),
+    "mk_layernorm": ("i", "pippfpiipiiiiiiiiiip"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
-    "mk_conv3x3": ("i", "pliplipilplppiliiiiiipip"),
+    "mk_bordered_rows": ("l", "iii"),
+    "mk_conv3x3": ("i", "pliplipilplplpiliiiiiiip"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
     "mk_linattn_work_floats": ("l", "iiii"),
     "mk_linattn_kv": ("i", "pppiiiip"),

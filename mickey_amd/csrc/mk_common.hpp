@@ -116,6 +116,44 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, void
 // logical chunk (MI355X: 64 banks x 4 B, b128 reads serviced in 4 groups of 16 lanes).
 __device__ __forceinline__ int swz8(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// ---- bordered NHWC feature maps (the activations the 3x3 convolutions read) -----------------------------------------
+// Pixel (b, y, x) of a [nimg, H, Wd] grid lives at row  ((b (H+1) + y + 1) (Wd+1) + x + 1)  of a buffer whose other rows
+// are zero and are never written: grid rows are Wd+1 pixels apart (the gap is the right border of one row AND the left
+// border of the next), images H+1 grid rows apart (the gap row is the bottom border of one image and the top border of
+// the next).  A 3x3 tap (dy, dx) of ANY pixel is then the row  +dy (Wd+1) + dx  -- a wave-uniform shift, no border test,
+// no zero page: an A piece of the implicit GEMM is one SGPR-base LDS-DMA instruction like a dense operand's.
+// Buffer rows: (nimg (H+1) + 1)(Wd+1) + 1.  With m = (b H + y) Wd + x the dense row index:
+//   row(m) = m + q + (b + 1)(Wd + 1) + 1,   q = m / Wd,  b = q / H.
+__host__ __device__ __forceinline__ long long bordered_rows(long long nimg, int H, int Wd) {
+  return (nimg * (H + 1) + 1) * (Wd + 1) + 1;
+}
+// walks the bordered row of dense row m in increasing steps (one pair of integer divisions at init, none per step)
+struct BorderedRow {
+  int x, y, extra;   // extra = row(m) - m
+  __device__ __forceinline__ void init(int m, int H, int Wd) {
+    const int q = m / Wd, b = q / H;
+    x = m - q * Wd;
+    y = q - b * H;
+    extra = q + (b + 1) * (Wd + 1) + 1;
+  }
+  __device__ __forceinline__ void step(int d, int H, int Wd) {
+    x += d;
+    while (x >= Wd) {
+      x -= Wd;
+      ++extra;
+      if (++y == H) {
+        y = 0;
+        extra += Wd + 1;
+      }
+    }
+  }
+};
+__device__ __forceinline__ long long bordered_row(int m, int H, int Wd) {
+  BorderedRow w;
+  w.init(m, H, Wd);
+  return (long long)m + w.extra;
+}
+
 // XCD-aware bijective remap of a linear block id: blocks that share an L2 get a contiguous id range
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;

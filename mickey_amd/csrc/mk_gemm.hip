@@ -7,9 +7,9 @@
 //     bias / GELU / LayerScale+residual / QKV-split epilogues fused,
 //   * the 14x14 patch embedding (reference layers/patch_embed.py:66,76) after an im2col pass,
 //   * the heads' 3x3 convolutions as an implicit GEMM (reference utils/extractor_utils.py:18-35):
-//     the A tile is gathered straight from the NHWC activation (one 3x3 tap per 64-wide K tile,
-//     out-of-image taps read a zero page), BatchNorm is folded into W/bias on the host and the
-//     1x1 shortcut conv rides along as extra K columns.
+//     the A tile comes straight from the BORDERED NHWC activation (mk_common.hpp; one 3x3 tap per 64-wide K
+//     tile = one row shift, the padding zeros are part of the buffer), BatchNorm is folded into W/bias on the
+//     host and the 1x1 shortcut conv rides along as extra K columns.
 //
 // Structure (MI355X): two instantiations of one body -- 128x128x64 tile / 4 waves (2x2, 64x64 per wave) and
 // 256x256x64 tile / 8 waves (2x4, 128x64 per wave) -- built from v_mfma_f32_16x16x32 fragments.  Operands go HBM -> LDS directly (global_load_lds, 16 B/lane),
@@ -141,7 +141,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   // the 256x256 kernels address operands with 32-bit element offsets and run a software pipeline of >= 2 K stages
   // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
   const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
-                    (AMODE == A_DENSE || (long long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
+                    (AMODE == A_DENSE || bordered_rows(p.M / (p.H * p.Wd), p.H, p.Wd) * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
   const bool ln_fold = p.ln_stats || p.xh;
   if (dtype == MK_F32) {   // exact parity mode: one plain schedule, LayerNorm as its own kernel
     MK_CHECK_ARG(!ln_fold, "gemm: the folded-LayerNorm epilogues exist for 16-bit operands only");
@@ -322,22 +322,25 @@ int mk_gemm_patch_embed_ln(const void* A, int lda, const void* W, int ldw, const
   return launch<A_DENSE>(p, 1, dtype, (hipStream_t)stream);
 }
 
+long long mk_bordered_rows(int nimg, int H, int Wd) { return bordered_rows(nimg, H, Wd); }
+
 int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, long long stride_in2, int C2, const void* W,
-               int ldw, long long strideW, const float* bias, long long strideBias, const void* resid, void* out, int Cout,
-               long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_is_f32, const void* zero_page,
-               int dtype, mk_stream_t stream) {
+               int ldw, long long strideW, const float* bias, long long strideBias, const void* resid, long long strideResid,
+               void* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_kind, int dtype,
+               mk_stream_t stream) {
   GemmParams p = {};
   p.A = in1; p.A2 = in2; p.W = W;
   p.M = nimg * H * Wd; p.N = Cout; p.K = 9 * C1 + (in2 ? C2 : 0);
   p.ldw = ldw; p.strideA_g = stride_in1; p.strideA2_g = stride_in2; p.strideW_g = strideW;
   p.strideBias_g = strideBias; p.strideOut_g = strideOut;
-  p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2 ? C2 : 0; p.zero_page = zero_page;
-  p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout; p.resid_lp = resid;
-  if (out_is_f32) p.out_f32 = (float*)out; else p.out_lp = out;
+  p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2 ? C2 : 0;
+  p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout; p.resid_lp = resid; p.strideResid_g = strideResid;
+  if (out_kind == MK_CONV_OUT_F32) p.out_f32 = (float*)out; else p.out_lp = out;
+  p.bord_out = out_kind == MK_CONV_OUT_BORDERED;
   if (int e = check_common(p, dtype)) return e;
   MK_CHECK_ARG(C1 % (dtype == MK_F32 ? 32 : BK) == 0 && (!in2 || C2 % (dtype == MK_F32 ? 32 : BK) == 0),
                "mk_conv3x3: channel counts must be multiples of the K tile (%d)", dtype == MK_F32 ? 32 : BK);
-  MK_CHECK_ARG(zero_page && out && groups > 0 && H > 0 && Wd > 0, "mk_conv3x3: bad args");
+  MK_CHECK_ARG(out && groups > 0 && nimg > 0 && H > 0 && Wd > 0 && out_kind >= 0 && out_kind <= 2, "mk_conv3x3: bad args");
   return launch<A_CONV3>(p, groups, dtype, (hipStream_t)stream);
 }
 

@@ -15,14 +15,14 @@ enum AMode { A_DENSE = 0, A_CONV3 = 1 };
 
 struct GemmParams {
   // operands
-  const void* A;       // dense: [M, lda]; conv: NHWC activation of source 1
-  const void* A2;      // conv only: NHWC activation of source 2 (1x1 shortcut), may be null
+  const void* A;       // dense: [M, lda]; conv: bordered NHWC activation of source 1 (mk_common.hpp: bordered_rows)
+  const void* A2;      // conv only: bordered NHWC activation of source 2 (1x1 shortcut), may be null
   const void* W;       // [N, ldw]
   int M, N, K, lda, ldw;
   long long strideA_g, strideA2_g, strideW_g;  // element strides per group (blockIdx.y)
   // conv geometry
   int H, Wd, C1, C2;   // image grid, channels of source 1 / source 2
-  const void* zero_page;
+  int bord_out;        // conv: the 16-bit output is written in the bordered layout too (it feeds the next conv)
   // epilogue
   int epi;
   int act;
@@ -33,7 +33,8 @@ struct GemmParams {
   void* out_lp;
   int ldc;
   long long strideOut_g;
-  const void* resid_lp;  // identity residual, [M, ldc] low precision
+  const void* resid_lp;  // identity residual, [M, ldc] low precision; conv: bordered like A, group stride strideResid_g
+  long long strideResid_g;
   // qkv split
   void* q;
   void* k;
@@ -263,9 +264,7 @@ struct Stager {
   const T* A;
   const T* A2;
   const T* wrow[WJ];
-  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: pixel index of the row
-  int ay[AJ], ax[AJ];
-  bool avalid[AJ];
+  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: bordered row of the pixel
   int wave, srow, sp;
 
   __device__ __forceinline__ void init(const GemmParams& p, int g, int m0, int n0, int wave_, int lane) {
@@ -286,17 +285,9 @@ struct Stager {
     for (int j = 0; j < AJ; ++j) {
       const int r = (wave * AJ + j) * 8 + srow;
       int m = m0 + r;
-      avalid[j] = m < p.M;
-      m = avalid[j] ? m : p.M - 1;
-      if (AMODE == A_DENSE) {
-        aoff[j] = (long long)m * p.lda + swz8(r, sp) * EPC<T>;
-        ay[j] = ax[j] = 0;
-      } else {
-        const int pix = m % (p.H * p.Wd);
-        ay[j] = pix / p.Wd;
-        ax[j] = pix % p.Wd;
-        aoff[j] = m;
-      }
+      m = m < p.M ? m : p.M - 1;
+      if (AMODE == A_DENSE) aoff[j] = (long long)m * p.lda + swz8(r, sp) * EPC<T>;
+      else aoff[j] = bordered_row(m, p.H, p.Wd);
     }
   }
 
@@ -309,27 +300,22 @@ struct Stager {
       // wave-uniform: which source / tap does this K tile belong to
       const int kc = 9 * p.C1;
       const T* src;
-      int cs, c0, dy, dx;
+      int cs, c0, shift = 0;   // shift: the tap in bordered rows (out-of-image taps land on zero border rows)
       if (k0 < kc) {
         const int tap = k0 / p.C1;
         c0 = k0 - tap * p.C1;
-        dy = tap / 3 - 1;
-        dx = tap % 3 - 1;
+        shift = (tap / 3 - 1) * (p.Wd + 1) + tap % 3 - 1;
         src = A;
         cs = p.C1;
       } else {
         c0 = k0 - kc;
-        dy = dx = 0;
         src = A2;
         cs = p.C2;
       }
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
         const int r = (wave * AJ + j) * 8 + srow;
-        const int yy = ay[j] + dy, xx = ax[j] + dx;
-        const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-        const T* s = ok ? src + (aoff[j] + dy * p.Wd + dx) * cs + c0 + swz8(r, sp) * EPC<T> : (const T*)p.zero_page + sp * EPC<T>;
-        glds16(s, sA + (wave * AJ + j) * 1024);
+        glds16(src + (aoff[j] + shift) * cs + c0 + swz8(r, sp) * EPC<T>, sA + (wave * AJ + j) * 1024);
       }
     }
 #pragma unroll
@@ -426,6 +412,8 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
       img = m / p.npatch;
       tok = m - img * p.npatch;
     }
+    // conv (H > 0): the identity residual and, with bord_out, the 16-bit output are bordered feature maps
+    const long long brow = (EPI == MK_EPI_STORE && p.H > 0) ? bordered_row(m, p.H, p.Wd) : (long long)m;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = nb + ni * 16;
@@ -435,7 +423,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
       else if (HAS_BIAS) v += bv[ni];
       if (EPI == MK_EPI_STORE) {
         if (p.resid_lp) {
-          const V4 r = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
+          const V4 r = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideResid_g + brow * p.ldc + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
         }
@@ -451,7 +439,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
           V4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
-          *(V4*)((T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = o;
+          *(V4*)((T*)p.out_lp + (long long)g * p.strideOut_g + (p.bord_out ? brow : (long long)m) * p.ldc + n) = o;
         }
       } else if (EPI == MK_EPI_LS_RESIDUAL) {
         float* x = p.out_f32 + (long long)m * p.ldc + n;
@@ -528,7 +516,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // SPLIT (split residual stream, §2.1b of DESIGN.md) is instantiated for INTERIOR tiles only (no row / column predicates:
 // straight-line code; with per-row branches this variant pushed the whole kernel over 256 VGPRs and hipcc spilled half the
 // accumulators of every tile of every launch) -- edge tiles take the direct epilogue; FIN: fp32 rows out (last block).
-template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false, bool FIN = false>
+template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false, bool FIN = false, bool CONV = false>
 __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
                                                   int wn, int lane, int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
@@ -596,6 +584,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int r = mi * 16 + fr;
+      // identity residual of a conv: a bordered feature map (one launch per forward takes this path)
+      const long long rrow = (CONV && p.resid_lp) ? bordered_row(min(mw + r, p.M - 1), p.H, p.Wd) : 0;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 v = acc[mi][ni];
@@ -604,10 +594,10 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         if (EPI == MK_EPI_QKV) {
           if (which == 0) v *= p.qscale;
         } else {
-          if (p.resid_lp) {
+          if (CONV && p.resid_lp) {
             const int m = mw + r, n = nw + fg * 4 + ni * 16;
             if (m < p.M && n < p.N) {
-              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n);
+              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideResid_g + rrow * p.ldc + n);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
             }
@@ -628,11 +618,17 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     }
     const int rr = lane >> 3, c = lane & 7;
     const int n = nw + c * 8;
+    // conv output that feeds the next conv: bordered rows (walked: the lane's rows are 8 apart)
+    const bool bord = CONV && p.bord_out;
+    BorderedRow bw;
+    if (bord) bw.init(mw + rr, p.H, p.Wd);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int r = it * 8 + rr;
       const int m = mw + r;
       const V8 val = *(const V8*)(wl + r * 128 + ((c ^ (r & 7)) << 4));
+      const int extra = bord ? bw.extra : 0;
+      if (bord) bw.step(8, p.H, p.Wd);
       if (m >= p.M || n >= p.N) continue;
       T* dst;
       if (EPI == MK_EPI_QKV) {
@@ -640,7 +636,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         img_tok(r, img, tok);
         dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
       } else {
-        dst = (T*)p.out_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + n;
+        dst = (T*)p.out_lp + (long long)g * p.strideOut_g + ((long long)m + extra) * p.ldc + n;
       }
       if (n + 8 <= p.N) {
         *(V8*)dst = val;
@@ -698,15 +694,16 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int r = mi * 16 + fr;
+        const long long rrow = (CONV && p.resid_lp) ? bordered_row(min(mw + half * 64 + r, p.M - 1), p.H, p.Wd) : 0;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           f32x4 v = acc[half * 4 + mi][ni];
           if (HAS_BIAS && !SPLIT) v += bv[ni];
           if (EPI == MK_EPI_STORE) {
-            if (p.resid_lp) {
+            if (CONV && p.resid_lp) {
               const int m = mw + half * 64 + r, nn = nw + fg * 4 + ni * 16;
               if (m < p.M && nn < p.N) {
-                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideOut_g + (long long)m * p.ldc + nn);
+                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideResid_g + rrow * p.ldc + nn);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
               }
@@ -807,7 +804,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 // with the plain ones).  0 = the plain epilogues, 1 = folded-LayerNorm consumer (QKV / bias (+GELU) with row parameters),
 // 2 = folded-LayerNorm producer (split residual stream), 3 = the same writing fp32 rows (last block): 2 and 3 together in
 // one kernel spill again.
-template <typename T, int KIND>
+template <typename T, int KIND, bool CONV = false>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
                                              int lane, int g, const float2* lnp = nullptr) {
   if constexpr (KIND == 2 || KIND == 3) {
@@ -832,19 +829,19 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8
     else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
     else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
   } else {
-    switch (p.epi) {   // wave-uniform, once per output tile
+    switch (CONV ? MK_EPI_STORE : p.epi) {   // wave-uniform, once per output tile (a conv only ever stores)
       case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
       case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
       case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
       default:
         if (!p.bias) {
-          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
         } else {
-          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
         }
     }
   }

@@ -44,9 +44,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   const int m0 = tm * BM, n0 = tn * BN;
   // this wave's 4 A pieces (own half) and 4 W pieces of a stage; piece = 8 rows x 128 B
   // (32-bit element offsets: the launcher routes operands of 2^31 elements or more to the 128x128 kernel)
-  unsigned woff[4], aoff[4];
-  int ay[4], ax[4];
-  bool avalid[4];
+  unsigned woff[4], aoff[4], aoff2[4];   // aoff2: conv, the same rows of source 2 (other channel count)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int rw = (wave * 4 + j) * 8 + srow;
@@ -55,54 +53,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     woff[j] = ((unsigned)n * (unsigned)p.ldw + swz8(rw, sp) * 8) * (unsigned)sizeof(T);   // bytes (< 2^32: see launch())
     const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
     int m = m0 + ra;
-    avalid[j] = m < p.M;
-    m = avalid[j] ? m : p.M - 1;
+    m = m < p.M ? m : p.M - 1;
     if (AMODE == A_DENSE) {
       aoff[j] = ((unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
-      ay[j] = ax[j] = 0;
-    } else {
-      const int pix = m % (p.H * p.Wd);
-      ay[j] = pix / p.Wd;
-      ax[j] = pix % p.Wd;
-      aoff[j] = m;
+      aoff2[j] = 0;
+    } else {   // the pixel's row in the bordered feature maps (mk_common.hpp): a tap is a wave-uniform shift of it
+      const unsigned br = (unsigned)bordered_row(m, p.H, p.Wd);
+      aoff[j] = (br * (unsigned)p.C1 + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
+      aoff2[j] = (br * (unsigned)p.C2 + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
     }
   }
   auto dma_w1 = [&](int s, int j) {
     // wave-uniform base (SGPRs) + the lane's constant 32-bit byte offset: no VALU instruction per piece
     glds16_sv(W + s * BK, woff[j], smem + (s & 1) * STAGE_BYTES + A_BYTES + (wave * 4 + j) * 1024);
   };
-  // conv: which tap / source a K stage belongs to is wave-uniform and the same for the 4 pieces of the stage: computed
-  // once per stage (it holds two integer divisions), not once per piece inside the MFMA slot
-  struct Tap { const T* src; int cs, c0, dy, dx; };
-  auto conv_tap = [&](int s) {
-    Tap t = {nullptr, 0, 0, 0, 0};
-    if (AMODE != A_DENSE) {
-      const int k0 = s * BK, kc = 9 * p.C1;
-      if (k0 < kc) {
-        const int tap = k0 / p.C1;
-        t.c0 = k0 - tap * p.C1;
-        t.dy = tap / 3 - 1;
-        t.dx = tap % 3 - 1;
-        t.src = A;
-        t.cs = p.C1;
-      } else {
-        t.c0 = k0 - kc;
-        t.src = A2;
-        t.cs = p.C2;
-      }
-    }
-    return t;
+  // conv: A stages are issued in K order (0, 1, 2, ...), so where the NEXT stage reads -- source, 3x3 tap, first channel,
+  // folded into one wave-uniform base pointer -- is running scalar state, advanced once per stage.  K = 9 taps x C1 channels of source 1, then C2 channels of source 2
+  // (the 1x1 shortcut) at the pixel itself.
+  const T* cbase = AMODE == A_DENSE ? A : A - (long long)(p.Wd + 2) * p.C1;   // tap (-1, -1), channel 0
+  int cleft = p.C1, ctap = 0;
+  auto conv_advance = [&]() {
+    cleft -= BK;
+    const bool wrap = cleft == 0;
+    ctap += wrap ? 1 : 0;
+    const int ty = (ctap * 11) >> 5, tx = ctap - 3 * ty;   // ctap / 3, ctap % 3 for 0 <= ctap < 9
+    const T* tapbase = ctap < 9 ? A + (long long)((ty - 1) * (p.Wd + 1) + tx - 1) * p.C1 : A2;
+    cbase = wrap ? tapbase : cbase + BK;
+    cleft = wrap ? (ctap < 9 ? p.C1 : p.C2) : cleft;
   };
-  auto dma_a1 = [&](int s, int j, const Tap& t) {
+  auto dma_a1 = [&](int s, int j) {
     char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
     if (AMODE == A_DENSE) {
       glds16_sv(A + s * BK, aoff[j], dst);
     } else {
-      const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
-      const int yy = ay[j] + t.dy, xx = ax[j] + t.dx;
-      const bool ok = avalid[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-      const T* sp_ = ok ? t.src + ((long long)aoff[j] + t.dy * p.Wd + t.dx) * t.cs + t.c0 + swz8(ra, sp) * 8 : (const T*)p.zero_page + sp * 8;
-      glds16(sp_, dst);
+      glds16_sv(cbase, ctap < 9 ? aoff[j] : aoff2[j], dst);   // the caller advances behind the 4th piece
     }
   };
   auto dma_w = [&](int s) {
@@ -110,9 +94,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     for (int j = 0; j < 4; ++j) dma_w1(s, j);
   };
   auto dma_a = [&](int s) {
-    const Tap t = conv_tap(s);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_a1(s, j, t);
+    for (int j = 0; j < 4; ++j) dma_a1(s, j);
+    if (AMODE != A_DENSE) conv_advance();
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -135,16 +119,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   for (int i = 0; i < WMF; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s.  Dense operands: a piece is one SALU-addressed instruction and
-  // goes out BETWEEN the MFMAs (behind MFMA 3, 11, 19, 27), pinned.  Conv: every piece needs ~15 VALU instructions of
-  // per-lane address arithmetic (tap shift, border test, zero page), which inside (or right behind) the MFMA stream cost
-  // more than they hide (conv layers 13.6 / 11.9 vs 10.2 ms per step): the conv pieces of stage kt+1 go out in the
-  // wave-row's NON-MFMA slot instead (first fragment slot of stage kt, next to the W pieces), where the other wave-row
-  // owns the matrix pipe and this row's VALU is idle.
-  constexpr bool A_IN_MFMA_SLOT = AMODE == A_DENSE;
+  // 32 MFMAs of a C slot; DMA: the 4 A pieces of stage s.  A piece is one SALU-addressed instruction (dense rows, and
+  // conv rows alike since the feature maps are bordered: round 2's conv pieces were ~15 VALU instructions of per-lane tap /
+  // border arithmetic each and had to go out in the wave-row's non-MFMA slot) and goes out BETWEEN the MFMAs (behind MFMA
+  // 3, 11, 19, 27), pinned.
   auto mfma32 = [&](const V8* wf, const V8* xf, auto dma, int s) {
-    constexpr bool DMA = decltype(dma)::value && A_IN_MFMA_SLOT;
-    const Tap t = Tap{nullptr, 0, 0, 0, 0};
+    constexpr bool DMA = decltype(dma)::value;
     __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -153,12 +133,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
       if (DMA && (q & 7) == 3) {
         __builtin_amdgcn_sched_barrier(0);
-        dma_a1(s, q >> 3, t);
+        dma_a1(s, q >> 3);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
+    if (DMA && AMODE != A_DENSE) conv_advance();   // behind the slot's MFMAs: hipcc turns its selects into a branch
   };
   auto bar = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -172,17 +153,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   auto stage0 = [&](int kt, auto next1, auto next2) {
     bar();   // slot 4kt
     load_frags(wf, xf, kt & 1, 0);
-    if constexpr (decltype(next1)::value) {
-      dma_w(kt + 1);
-      if constexpr (!A_IN_MFMA_SLOT) dma_a(kt + 1);
-    }
+    if constexpr (decltype(next1)::value) dma_w(kt + 1);
     bar();                      // slot 4kt+1
     mfma32(wf, xf, No{}, 0);
     bar();                      // slot 4kt+2
     load_frags(wf, xf, kt & 1, 1);
     bar();                      // slot 4kt+3
     mfma32(wf, xf, next2, kt + 2);
-    if constexpr (decltype(next2)::value && A_IN_MFMA_SLOT)
+    if constexpr (decltype(next2)::value)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,10 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   auto stage1 = [&](int kt, auto next1, auto next2) {
     bar();                      // slot 4kt+1
     load_frags(wf, xf, kt & 1, 0);
-    if constexpr (decltype(next1)::value) {
-      dma_w(kt + 1);
-      if constexpr (!A_IN_MFMA_SLOT) dma_a(kt + 1);
-    }
+    if constexpr (decltype(next1)::value) dma_w(kt + 1);
     bar();                      // slot 4kt+2
     mfma32(wf, xf, No{}, 0);
     bar();                      // slot 4kt+3
@@ -221,18 +196,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   if constexpr (PRODUCER) shl.issue(p, m0, tid, 256);
   dma_a(0);
   dma_w(0);
-  if constexpr (A_IN_MFMA_SLOT) dma_a(1);
+  dma_a(1);
   const bool publish = ln && p.ln_shift_out != nullptr && n0 == 0;   // first tile column: the row means for the next producer
   if (ln_fast) lnl.template finish<12>(p, tid, (float2*)(smem + 2 * STAGE_BYTES), m0, publish);   // 12 DMA pieces are younger than the loads
 #ifndef MK_LN_NO_SLOW
   else if (ln) ln_params_to_lds<256, 512>(p, m0, tid, (float2*)(smem + 2 * STAGE_BYTES), publish);
 #endif
   if constexpr (PRODUCER) shl.template finish<12>(tid, 256, (float*)(smem + 2 * STAGE_BYTES));
-  if constexpr (A_IN_MFMA_SLOT) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if (wm == 0) {
     for (int kt = 0; kt < nk - 2; ++kt) stage0(kt, Yes{}, Yes{});
     stage0(nk - 2, Yes{}, No{});
@@ -244,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     stage1(nk - 2, Yes{}, No{});
     stage1(nk - 1, No{}, No{});
   }
-  epilogue_lds<T, KIND>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g, (const float2*)(smem + 2 * STAGE_BYTES));
+  epilogue_lds<T, KIND, AMODE == A_CONV3>(p, acc, smem + wave * 16384, m0, n0, wm, wn, lane, g, (const float2*)(smem + 2 * STAGE_BYTES));
 }
 
 template <typename T, int AMODE, int KIND>

@@ -19,7 +19,8 @@ template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
-                                                        int rows_per_img, int skip, int wgroup_rows) {
+                                                        int rows_per_img, int skip, int wgroup_rows, int bord_h, int bord_w,
+                                                        int bord_m) {
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
   if (r0 >= rows_out) return;
@@ -55,6 +56,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (r >= rows_out) break;
     if (rr + 1 < LN_RPW && r + 1 < rows_out) load_row(r + 1, v[(rr + 1) & 1]);
     f32x4 (&cur)[MAXV] = v[rr & 1];
+    // bordered output (feeds a 3x3 conv, mk_common.hpp): buffers of bord_m pixels each, one behind the other
+    long long ro = r;
+    if (bord_h > 0) {
+      const int gb = r / bord_m, m = r - gb * bord_m;
+      ro = gb * bordered_rows(bord_m / (bord_h * bord_w), bord_h, bord_w) + bordered_row(m, bord_h, bord_w);
+    }
     const float* wr = w;
     const float* br = b;
     if (wgroup_rows > 0) {  // one (w, b) per block of wgroup_rows output rows
@@ -96,12 +103,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
         if (out) {
           if (out_is_f32) {
-            *(f32x4*)((float*)out + (long long)r * ldo + c) = y;
+            *(f32x4*)((float*)out + ro * ldo + c) = y;
           } else {
             typename Lp<T>::V4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
-            *(typename Lp<T>::V4*)((T*)out + (long long)r * ldo + c) = o;
+            *(typename Lp<T>::V4*)((T*)out + ro * ldo + c) = o;
           }
         }
       }
@@ -229,9 +236,11 @@ int mk_version(void) { return 100; }
 const char* mk_last_error(void) { return g_err; }
 
 int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
-                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int dtype,
-                 mk_stream_t stream) {
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
+                 int bord_w, int bord_m, int dtype, mk_stream_t stream) {
   MK_CHECK_ARG(x && w && b && (out || resid), "mk_layernorm: null pointer");
+  MK_CHECK_ARG(bord_h == 0 || (bord_h > 0 && bord_w > 0 && bord_m > 0 && bord_m % (bord_h * bord_w) == 0 && rows_out % bord_m == 0),
+               "mk_layernorm: bordered output needs rows_out = k * bord_m, bord_m = nimg * bord_h * bord_w");
   MK_CHECK_ARG(D > 0 && D % 4 == 0 && D <= LN_MAXV * 256, "mk_layernorm: D=%d must be a multiple of 4 and <= %d", D,
                LN_MAXV * 256);
   MK_CHECK_ARG(rows_out > 0 && rows_per_img > skip && skip >= 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
@@ -239,7 +248,7 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
 #define MK_LN(T_, V_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m)
   if (dtype == MK_BF16) {
     if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
   } else if (dtype == MK_F16) {

@@ -135,8 +135,9 @@ def cls_token(cls, pos, x, nimg, ntok, D):
 
 
 def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows_out=None, rows_per_img=None, skip=0,
-              ldo=None, wgroup_rows=0, ldx=None, ldr=None):
-    """LayerNorm rows of fp32 x [rows, D]; see mk_layernorm for the row remap and the residual form."""
+              ldo=None, wgroup_rows=0, ldx=None, ldr=None, bordered=None):
+    """LayerNorm rows of fp32 x [rows, D]; see mk_layernorm for the row remap and the residual form.
+    bordered = (nimg, H, W): `out` is a stack of bordered feature maps (rows_out = k * nimg * H * W pixels)."""
     D = w.shape[-1]
     rows_in = x.numel() // x.shape[-1]
     if rows_per_img is None:
@@ -148,9 +149,10 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
     is_f32 = out is not None and out.dtype == torch.float32
     ldo = (out.stride(-2) if out is not None else D) if ldo is None else ldo
     lp = out.dtype if (out is not None and not is_f32) else torch.bfloat16
+    bh, bw, bm = (bordered[1], bordered[2], bordered[0] * bordered[1] * bordered[2]) if bordered else (0, 0, 0)
     call("mk_layernorm", ptr(x), x.stride(-2) if ldx is None else ldx, ptr(w), ptr(b), float(eps), ptr(out), ldo, int(is_f32),
          ptr(resid), (resid.stride(-2) if resid is not None else D) if ldr is None else ldr, rows_out, D, rows_per_img, skip,
-         wgroup_rows, dtype_code(lp), stream())
+         wgroup_rows, bh, bw, bm, dtype_code(lp), stream())
     return out
 
 
@@ -165,11 +167,33 @@ def flash_attn(q, k, vt, out, nimg, heads, ntok, ntok_pad):
     return out
 
 
-def conv3x3(in1, C1, w, bias, out, Cout, groups, nimg, H, W, zero_page, act=ACT_NONE, in2=None, C2=0, resid=None,
-            stride_in1=0, stride_in2=0, stride_w=0, stride_bias=0, stride_out=0):
+CONV_OUT_DENSE, CONV_OUT_BORDERED, CONV_OUT_F32 = 0, 1, 2
+
+
+def bordered_rows(nimg, H, W):
+    """Rows of a bordered feature map of nimg H x W grids (mickey_hip.h: mk_bordered_rows)."""
+    return int(query("mk_bordered_rows", nimg, H, W))
+
+
+def bordered_empty(lead, nimg, H, W, C, dtype, device):
+    """Zeroed stack of bordered feature maps, [*lead, mk_bordered_rows, C]: the border rows stay zero for ever."""
+    return torch.zeros(tuple(lead) + (bordered_rows(nimg, H, W), C), dtype=dtype, device=device)
+
+
+def bordered_index(nimg, H, W, device):
+    """Row of pixel (b, y, x) in a bordered feature map, int64 [nimg * H * W] (tests, tools)."""
+    b, y, x = torch.meshgrid(torch.arange(nimg, device=device), torch.arange(H, device=device),
+                             torch.arange(W, device=device), indexing="ij")
+    return (((b * (H + 1) + y + 1) * (W + 1)) + x + 1).reshape(-1)
+
+
+def conv3x3(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, resid=None,
+            stride_in1=0, stride_in2=0, stride_w=0, stride_bias=0, stride_out=0, stride_resid=0, out_bordered=False):
+    """in1 / in2 / resid: bordered feature maps; out: fp32 dense rows, or lp dense / bordered rows (mk_conv3x3)."""
+    kind = CONV_OUT_F32 if out.dtype == torch.float32 and in1.dtype != torch.float32 else \
+        (CONV_OUT_BORDERED if out_bordered else CONV_OUT_DENSE)
     call("mk_conv3x3", ptr(in1), stride_in1, C1, ptr(in2), stride_in2, C2, ptr(w), w.shape[-1], stride_w, ptr(bias), stride_bias,
-         ptr(resid), ptr(out), Cout, stride_out, groups, nimg, H, W, act, int(out.dtype == torch.float32), ptr(zero_page),
-         dtype_code(in1.dtype), stream())
+         ptr(resid), stride_resid, ptr(out), Cout, stride_out, groups, nimg, H, W, act, kind, dtype_code(in1.dtype), stream())
     return out
 
 

@@ -78,31 +78,35 @@ def encoder_forward(W, ws, img):
             ops.layernorm(x, blk.n2w, blk.n2b, 1e-6, out=y)
             ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
             ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
-    feat = ws.get("feat", (nimg * npatch, D), getattr(W, "lp_heads", lp), dev)   # the heads' operand type
-    ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1)
+    # the heads' operand type, as a BORDERED feature map (mickey_hip.h: what a 3x3 conv reads; border rows stay zero)
+    feat = ws.get("feat", (ops.bordered_rows(nimg, gh, gw), D), getattr(W, "lp_heads", lp), dev, zero=True)
+    ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
+                  bordered=(nimg, gh, gw))
     return feat, gh, gw
 
 
 def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
-    """feat lp [nimg*n, D] -> scr [nimg,1,n], kps [nimg,2,n] (absolute pixels), depth [nimg,1,n],
-    dsc [nimg,Cd,n], all fp32."""
+    """feat lp, bordered feature map of nimg gh x gw grids [bordered_rows, D] -> scr [nimg,1,n], kps [nimg,2,n]
+    (absolute pixels), depth [nimg,1,n], dsc [nimg,Cd,n], all fp32.  Every activation a 3x3 conv reads is bordered (zeroed
+    once at allocation, the kernels write pixels only); what only row-wise kernels read is dense."""
     dev, lp = feat.device, getattr(W, "lp_heads", W.lp)
     n = gh * gw
     M = nimg * n
     G = 4
     mk = cfg["MICKEY"]
-    zp = W.zero_page
+    R = ops.bordered_rows(nimg, gh, gw)
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
     for bi, rb in enumerate(W.rb):
         co = rb.cout
-        h1 = ws.get("rb%d_h" % bi, (G, M, co), lp, dev)
-        ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, zp, act=ops.ACT_RELU, stride_in1=s_in,
-                    stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=M * co)
-        xo = ws.get("rb%d_x" % bi, (G, M, co), lp, dev)
-        ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, zp, act=ops.ACT_RELU, in2=x_in, C2=c_in,
-                    stride_in1=M * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
-                    stride_out=M * co)
-        x_in, c_in, s_in = xo, co, M * co
+        last = bi == len(W.rb) - 1   # its output feeds the attention layers (row-wise kernels): dense rows
+        h1 = ws.get("rb%d_h" % bi, (G, R, co), lp, dev, zero=True)
+        ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
+                    stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
+        xo = ws.get("rb%d_x" % bi, (G, M if last else R, co), lp, dev, zero=not last)
+        ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=x_in, C2=c_in,
+                    stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
+                    stride_out=(M if last else R) * co, out_bordered=not last)
+        x_in, c_in, s_in = xo, co, R * co
     C = c_in  # 128
     # ---- Transformer_self_att: 3 linear-attention encoder layers, residual stream in fp32 ----
     xs = ws.get("att_xs", (G, M, C), torch.float32, dev)
@@ -120,7 +124,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     msg = ws.get("att_msg", (G, M, C), lp, dev)
     mrg = ws.get("att_mrg", (G, M, C), torch.float32, dev)
     hid = ws.get("att_hid", (G, M, 2 * C), lp, dev)
-    x4 = ws.get("att_out", (G, M, C), lp, dev)
+    x4 = ws.get("att_out", (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
     nl = len(W.att)
     for li, lay in enumerate(W.att):
         ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
@@ -134,22 +138,23 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
         ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
         last = li == nl - 1
         ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=x4 if last else cat, ldo=C if last else 2 * C, resid=xs,
-                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M)
+                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None)
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout
-    h4 = ws.get("rb4_h", (3, M, ck), lp, dev)
-    ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, zp, act=ops.ACT_RELU, stride_in1=M * C,
-                stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=M * ck)
+    h4 = ws.get("rb4_h", (3, R, ck), lp, dev, zero=True)
+    ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
+                stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
     f4 = ws.get("rb4_f", (3, M, ck), torch.float32, dev)
-    ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, zp, act=ops.ACT_RELU,
-                in2=x4 if kpw.has_sc else None, C2=C, resid=None if kpw.has_sc else x4, stride_in1=M * ck,
-                stride_in2=M * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
+    ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
+                in2=x4 if kpw.has_sc else None, C2=C, resid=None if kpw.has_sc else x4, stride_in1=R * ck,
+                stride_in2=R * C, stride_resid=R * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck,
+                stride_out=M * ck)
     cd = dw.cout
-    hd = ws.get("rb4_hd", (M, cd), lp, dev)
-    ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, zp, act=ops.ACT_RELU)
+    hd = ws.get("rb4_hd", (R, cd), lp, dev, zero=True)
+    ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
-    ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, zp, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246
+    ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246
                 in2=x4[3] if dw.has_sc else None, C2=C, resid=None if dw.has_sc else x4[3])
     kh = mk["KP_HEADS"]
     return ops.head_tails(f4[0], W.w_score, f4[1], W.w_xy, f4[2], W.w_depth, fd, nimg, gh, gw, ck, cd, border=3,

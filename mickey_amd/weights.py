@@ -99,7 +99,6 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
             blk.fc1_wf, blk.fc1_cs, blk.fc1_bf = lp(wf), f32(cs), f32(bf)
         W.blocks.append(blk)
     W.norm_w, W.norm_b = f32(sd[p + "norm.weight"]), f32(sd[p + "norm.bias"])
-    W.zero_page = torch.zeros(256, device=dev, dtype=torch.uint8)
     W._pos_cache = {}
     W._pe_cache = {}
     return W

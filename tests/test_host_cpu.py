@@ -44,7 +44,9 @@ def test_abi_rejects_bad_arguments_without_a_device(nv):
     lib = nv.load()
     assert lib.mk_gemm(None, 0, None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
     assert b"gemm" in lib.mk_last_error()
-    assert lib.mk_layernorm(None, 0, None, None, 1e-6, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None) == 1
+    assert lib.mk_layernorm(None, 0, None, None, 1e-6, None, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None) == 1
+    assert nv.query("mk_bordered_rows", 2, 9, 7) == (2 * 10 + 1) * 8 + 1
+    assert lib.mk_conv3x3(None, 0, 64, None, 0, 0, None, 0, 0, None, 0, None, 0, None, 64, 0, 1, 1, 4, 4, 0, 3, 0, None) == 1   # out_kind 3
     # row partials (4 column chunks) + column partials (1 row block) + final LSE vectors + pad + the stored correlation
     assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 1) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4 + 2 * 10 * 12
     assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 0) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4
@@ -222,7 +224,8 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
         calls.clear()
         feat, gh, gw = pipeline.encoder_forward(W, pipeline.Workspace(), img)
         names = [c[0] for c in calls]
-        assert (gh, gw) == (6, 9) and feat.shape == (2 * 54, 128)
+        assert (gh, gw) == (6, 9) and feat.shape == (ops.bordered_rows(2, 6, 9), 128)   # bordered feature map
+        assert calls[-1][2]["bordered"] == (2, 6, 9)
         if fold:
             assert names == ["im2col", "gemm_patch_embed_ln", "cls_token_ln", "recentre_split"] + \
                 ["gemm_qkv_ln", "flash_attn", "gemm_ls_residual_ln", "gemm_ln", "gemm_ls_residual_ln"] * W.depth + ["layernorm"]
@@ -260,3 +263,25 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
                 ["layernorm", "gemm_qkv", "flash_attn", "gemm_ls_residual", "layernorm", "gemm", "gemm_ls_residual"] * W.depth + ["layernorm"]
     # fp32 operands never fold (the exact parity mode keeps LayerNorm as its own kernel)
     assert not weights.prepare_encoder(sd, torch.device("cpu"), torch.float32, prefix="", ln_fold=True).ln_fold
+
+
+def test_bordered_index_matches_the_library():
+    """the torch-side index helper (tests, tools) and mk_bordered_rows describe the same layout"""
+    from mickey_amd import ops
+    for nimg, H, W in ((1, 1, 1), (2, 9, 7), (3, 4, 11)):
+        idx = ops.bordered_index(nimg, H, W, "cpu")
+        assert idx.shape == (nimg * H * W,) and len(set(idx.tolist())) == idx.numel()
+        R = ops.bordered_rows(nimg, H, W)
+        assert R == (nimg * (H + 1) + 1) * (W + 1) + 1
+        # every 3x3 neighbour of every pixel is inside the buffer and is either a pixel of the same image or a border row
+        pix = set(idx.tolist())
+        for i, r in enumerate(idx.tolist()):
+            b, y, x = i // (H * W), (i // W) % H, i % W
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    n = r + dy * (W + 1) + dx
+                    assert 0 <= n < R
+                    inside = 0 <= y + dy < H and 0 <= x + dx < W
+                    assert (n in pix) == inside
+                    if inside:
+                        assert n == idx[(b * H + y + dy) * W + x + dx]

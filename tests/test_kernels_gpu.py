@@ -428,15 +428,25 @@ def test_flash_attention(dtype, ntok, nimg, heads, mode):
 
 
 
+def _to_bordered(x, nimg, H, W):
+    """dense NHWC rows [..., nimg*H*W, C] -> bordered feature map [..., bordered_rows, C] (zeros elsewhere)"""
+    from mickey_amd import ops
+    out = ops.bordered_empty(x.shape[:-2], nimg, H, W, x.shape[-1], x.dtype, x.device)
+    out[..., ops.bordered_index(nimg, H, W, x.device), :] = x
+    return out
+
+
 @pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("with_sc,with_res", [(False, False), (True, False), (False, True)])
-def test_conv3x3(with_sc, with_res, tile):
+@pytest.mark.parametrize("out_kind", ["f32", "dense", "bordered"])
+def test_conv3x3(with_sc, with_res, tile, out_kind):
     from mickey_amd import ops
     dev = _dev()
     ops.gemm_set_tile(tile)
     G, nimg, H, W, C1, C2, Cout = 3, 2, 9, 7, 128, 64, 128 if with_res else 192
     if with_res:
         Cout = C1
+    M = nimg * H * W
     x = torch.randn((G, nimg, H, W, C1), generator=g(1)).bfloat16()
     x2 = torch.randn((nimg, H, W, C2), generator=g(2)).bfloat16()
     wc = (torch.randn((G, Cout, C1, 3, 3), generator=g(3)) / math.sqrt(9 * C1)).bfloat16()
@@ -447,13 +457,25 @@ def test_conv3x3(with_sc, with_res, tile):
     w2d[:, :, : 9 * C1] = wc.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9 * C1)
     if with_sc:
         w2d[:, :, 9 * C1:] = ws
-    zero = torch.zeros(256, device=dev, dtype=torch.uint8)
-    out = torch.empty((G, nimg * H * W, Cout), device=dev, dtype=torch.float32)
-    xd = x.to(dev)
-    ops.conv3x3(xd, C1, w2d.to(dev), bias.to(dev), out, Cout, G, nimg, H, W, zero, act=ops.ACT_RELU,
-                in2=x2.to(dev) if with_sc else None, C2=C2, resid=xd if with_res else None,
-                stride_in1=nimg * H * W * C1, stride_in2=0, stride_w=Cout * K, stride_bias=Cout,
-                stride_out=nimg * H * W * Cout)
+    R = ops.bordered_rows(nimg, H, W)
+    xd = _to_bordered(x.reshape(G, M, C1).to(dev), nimg, H, W)          # [G, R, C1]
+    x2d = _to_bordered(x2.reshape(M, C2).to(dev), nimg, H, W)           # [R, C2], shared by the groups
+    if out_kind == "f32":
+        out = torch.empty((G, M, Cout), device=dev, dtype=torch.float32)
+    elif out_kind == "dense":
+        out = torch.empty((G, M, Cout), device=dev, dtype=torch.bfloat16)
+    else:   # border rows pre-filled with a sentinel: the kernel must not touch them
+        out = torch.full((G, R, Cout), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.conv3x3(xd, C1, w2d.to(dev), bias.to(dev), out, Cout, G, nimg, H, W, act=ops.ACT_RELU,
+                in2=x2d if with_sc else None, C2=C2, resid=xd if with_res else None,
+                stride_in1=R * C1, stride_in2=0, stride_w=Cout * K, stride_bias=Cout,
+                stride_out=out.shape[1] * Cout, stride_resid=R * C1, out_bordered=out_kind == "bordered")
+    if out_kind == "bordered":
+        idx = ops.bordered_index(nimg, H, W, dev)
+        mask = torch.ones(R, dtype=torch.bool, device=dev)
+        mask[idx] = False
+        assert bool((out[:, mask] == 7.0).all())
+        out = out[:, idx]
     for gi in range(G):
         ref = F.conv2d(x[gi].float().permute(0, 3, 1, 2), wc[gi].float(), padding=1) + bias[gi].view(1, -1, 1, 1)
         if with_sc:
@@ -461,7 +483,41 @@ def test_conv3x3(with_sc, with_res, tile):
         if with_res:
             ref = ref + x[gi].float().permute(0, 3, 1, 2)
         ref = F.relu(ref).permute(0, 2, 3, 1).reshape(-1, Cout)
-        assert rel(out[gi], ref) < 2e-5, (gi, rel(out[gi], ref))
+        tol = 2e-5 if out_kind == "f32" else 3e-3   # 16-bit outputs: one bf16 rounding
+        assert rel(out[gi].float(), ref) < tol, (gi, rel(out[gi].float(), ref))
+
+
+@pytest.mark.parametrize("nimg,H,W", [(64, 51, 38), (3, 5, 3)])
+def test_conv3x3_big_tiles_and_tiny_grids(nimg, H, W):
+    """the automatic schedule at the bench shape (256x256 ping-pong tiles: interior + edge tiles, rows walked in the LDS
+    epilogue across many image boundaries) and a grid narrower than the epilogue's row step (W < 8)"""
+    from mickey_amd import ops
+    dev = _dev()
+    ops.gemm_set_tile(0)
+    C1, Cout = 64, 256
+    M = nimg * H * W
+    x = torch.randn((M, C1), generator=g(1)).bfloat16().to(dev)
+    wc = (torch.randn((Cout, C1, 3, 3), generator=g(3)) / math.sqrt(9 * C1)).bfloat16()
+    w2d = wc.permute(0, 2, 3, 1).reshape(Cout, 9 * C1).contiguous().to(dev)
+    bias = torch.randn((Cout,), generator=g(5)).to(dev)
+    R = ops.bordered_rows(nimg, H, W)
+    xd = _to_bordered(x, nimg, H, W)
+    out = torch.full((R, Cout), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.conv3x3(xd, C1, w2d, bias, out, Cout, 1, nimg, H, W, act=ops.ACT_NONE, out_bordered=True)
+    idx = ops.bordered_index(nimg, H, W, dev)
+    mask = torch.ones(R, dtype=torch.bool, device=dev)
+    mask[idx] = False
+    assert bool((out[mask] == 7.0).all())
+    ref = F.conv2d(x.float().reshape(nimg, H, W, C1).permute(0, 3, 1, 2), wc.float().to(dev), padding=1) + bias.view(1, -1, 1, 1)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel(out[idx].float(), ref) < 3e-3
+    # and the chain: a second conv reading what the first one wrote (borders intact) == conv of the dense rows
+    out2 = torch.empty((M, Cout), device=dev, dtype=torch.float32)
+    out[mask] = 0
+    wc2 = (torch.randn((Cout, Cout, 3, 3), generator=g(7)) / math.sqrt(9 * Cout)).bfloat16()
+    ops.conv3x3(out, Cout, wc2.permute(0, 2, 3, 1).reshape(Cout, 9 * Cout).contiguous().to(dev), bias, out2, Cout, 1, nimg, H, W)
+    ref2 = F.conv2d(out[idx].float().reshape(nimg, H, W, Cout).permute(0, 3, 1, 2), wc2.float().to(dev), padding=1) + bias.view(1, -1, 1, 1)
+    assert rel(out2, ref2.permute(0, 2, 3, 1).reshape(M, Cout)) < 2e-5
 
 
 def test_grouped_gemm():

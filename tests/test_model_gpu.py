@@ -61,7 +61,12 @@ def test_vit_tiny_encoder_golden(golden):
         W = weights.prepare_encoder(sd, dev, dt, prefix="")
         feat, gh, gw = pipeline.encoder_forward(W, pipeline.Workspace(), img.to(dev))
         assert (gh, gw) == (6, 9)
-        e = rel(feat.float().reshape(2, 54, 128), g["tokens"])
+        from mickey_amd import ops
+        idx = ops.bordered_index(2, gh, gw, dev)          # feat is a bordered feature map (what the heads' convs read)
+        border = torch.ones(feat.shape[0], dtype=torch.bool, device=dev)
+        border[idx] = False
+        assert float(feat[border].float().abs().max()) == 0.0
+        e = rel(feat[idx].float().reshape(2, 54, 128), g["tokens"])
         assert e < tol, (dt, e)
 
 
