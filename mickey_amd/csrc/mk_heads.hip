@@ -49,17 +49,30 @@ __global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restric
   const float* base = qkv + gi * (long long)L * 3 * C;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ks = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    const float* row = base + (long long)s * 3 * C;
-    const float kd = phi(__builtin_nontemporal_load(row + C + h * 16 + d));
-    const f32x4 v0 = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + h * 16 + vh * 8));
-    const f32x4 v1 = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + h * 16 + vh * 8 + 4));
+  // four tokens per trip: all 12 loads of a trip are in flight before the first is consumed (one token per trip left the
+  // kernel waiting on a single HBM round trip per token: 2.4 TB/s); the accumulation order over tokens is unchanged
+  const float* col = base + h * 16;
+  for (int s = s0; s < s1; s += 4) {
+    float kr[4];
+    f32x4 v0[4], v1[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc[e] += kd * (v0[e] * invL);
-      acc[4 + e] += kd * (v1[e] * invL);
+    for (int u = 0; u < 4; ++u) {
+      const float* row = col + (long long)min(s + u, s1 - 1) * 3 * C;
+      kr[u] = __builtin_nontemporal_load(row + C + d);
+      v0[u] = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + vh * 8));
+      v1[u] = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + vh * 8 + 4));
     }
-    ks += kd;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s + u >= s1) break;
+      const float kd = phi(kr[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] += kd * (v0[u][e] * invL);
+        acc[4 + e] += kd * (v1[u][e] * invL);
+      }
+      ks += kd;
+    }
   }
   float* o = part + (((gi * H + h) * nchunk) + chunk) * KVW;
 #pragma unroll

@@ -116,6 +116,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// Narrow rows (D <= 128: the 128-channel LayerNorms of the heads' attention layers, 6 of the 7 stand-alone LayerNorms of a
+// forward).  In the kernel above such a row occupies half a wave and a wave has one 512-byte row in flight: 2.2 TB/s.
+// Here a row is 32 lanes x 4 floats, a wave works on TWO rows at a time and requests all 8 rows it owns (4 trips) before
+// it reduces the first.  Same arithmetic per row (sum, then squares about the mean, both over the row's 32 lanes).
+constexpr int LNN_TRIPS = 4;   // row pairs per wave
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float eps, void* out, int ldo,
+                                                               int out_is_f32, float* resid, int ldr, int rows_out, int D,
+                                                               int rows_per_img, int skip, int wgroup_rows, int bord_h,
+                                                               int bord_w, int bord_m) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = (lane & 31) * 4;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * LNN_TRIPS);
+  if (r0 >= rows_out) return;
+  const bool cok = c < D;
+  const int rpo = rows_per_img - skip;
+  f32x4 v[LNN_TRIPS];
+#pragma unroll
+  for (int t = 0; t < LNN_TRIPS; ++t) {
+    const int r = r0 + 2 * t + half;
+    v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < rows_out && cok) {
+      const long long rin = (long long)(r / rpo) * rows_per_img + skip + (r % rpo);
+      v[t] = __builtin_nontemporal_load((const f32x4*)(x + rin * ldx + c));
+    }
+  }
+  auto half_sum = [](float a) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    return a;
+  };
+#pragma unroll
+  for (int t = 0; t < LNN_TRIPS; ++t) {
+    const int r = r0 + 2 * t + half;
+    const bool ok = r < rows_out && cok;
+    const float mean = half_sum((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) / (float)D;
+    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cok) d = v[t] - mean;
+    const float rstd = 1.0f / sqrtf(half_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) / (float)D + eps);
+    if (!ok) continue;
+    const long long wo = wgroup_rows > 0 ? (long long)(r / wgroup_rows) * D : 0;
+    const f32x4 ww = *(const f32x4*)(w + wo + c), bb = *(const f32x4*)(b + wo + c);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = d[e] * rstd * ww[e] + bb[e];
+    if (resid) {
+      float* rp = resid + (long long)r * ldr + c;
+      y += *(const f32x4*)rp;
+      *(f32x4*)rp = y;
+    }
+    if (out) {
+      long long ro = r;
+      if (bord_h > 0) {
+        const int gb = r / bord_m, m = r - gb * bord_m;
+        ro = gb * bordered_rows(bord_m / (bord_h * bord_w), bord_h, bord_w) + bordered_row(m, bord_h, bord_w);
+      }
+      if (out_is_f32) {
+        *(f32x4*)((float*)out + ro * ldo + c) = y;
+      } else {
+        typename Lp<T>::V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
+        *(typename Lp<T>::V4*)((T*)out + ro * ldo + c) = o;
+      }
+    }
+  }
+}
+
 // one thread per 4 output columns (k = ch*196 + dy*14 + dx); rows = patches
 template <typename T>
 __global__ __launch_bounds__(256) void im2col14_kernel(const float* __restrict__ img, long long stride_img,
@@ -245,6 +313,18 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                LN_MAXV * 256);
   MK_CHECK_ARG(rows_out > 0 && rows_per_img > skip && skip >= 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0,
                "mk_layernorm: bad geometry");
+  if (D <= 128) {
+    dim3 gridn((rows_out + 8 * LNN_TRIPS - 1) / (8 * LNN_TRIPS));
+#define MK_LNN(T_)                                                                                                         \
+  hipLaunchKernelGGL((layernorm_narrow_kernel<T_>), gridn, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m)
+    if (dtype == MK_BF16) MK_LNN(__bf16);
+    else if (dtype == MK_F16) MK_LNN(_Float16);
+    else MK_LNN(float);
+#undef MK_LNN
+    MK_CHECK_LAUNCH();
+    return MK_OK;
+  }
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
 #define MK_LN(T_, V_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \

@@ -389,6 +389,34 @@ def test_layernorm(D):
     assert rel(rd, ref2) < 2e-6 and rel(o2.float(), ref2) < 4e-3
 
 
+@pytest.mark.parametrize("D", [64, 100, 128, 384])
+def test_layernorm_groups_and_bordered_output(D):
+    """the forms the heads use: one (w, b) per block of rows, residual update, output into a stack of bordered feature maps
+    (border rows untouched); D <= 128 takes the two-rows-per-wave kernel, ragged row counts included"""
+    from mickey_amd import ops
+    dev = _dev()
+    G, nimg, H, W = 3, 2, 5, 7
+    M = nimg * H * W
+    x = torch.randn((G * M, D), generator=g(1)) * 2 - 0.3
+    w, b = torch.randn((G, D), generator=g(2)), torch.randn((G, D), generator=g(3))
+    r = torch.randn((G * M, D), generator=g(4))
+    ref = torch.cat([F.layer_norm(x[i * M:(i + 1) * M], (D,), w[i], b[i], 1e-5) for i in range(G)]) + r
+    R = ops.bordered_rows(nimg, H, W)
+    for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 4e-3)):
+        out = torch.full((G, R, D), 7.0, device=dev, dtype=dt)
+        rd = r.to(dev)
+        ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-5, out=out, ldo=D, resid=rd, rows_out=G * M, rows_per_img=G * M,
+                      wgroup_rows=M, bordered=(nimg, H, W))
+        idx = ops.bordered_index(nimg, H, W, dev)
+        mask = torch.ones(R, dtype=torch.bool, device=dev)
+        mask[idx] = False
+        assert bool((out[:, mask] == 7.0).all())
+        assert rel(out[:, idx].reshape(G * M, D).float(), ref) < tol and rel(rd, ref) < 2e-6
+    # ragged: 13 rows (not a multiple of the rows a wave owns)
+    o = ops.layernorm(x[:13].to(dev), w[0].to(dev), b[0].to(dev), 1e-6, out_dtype=torch.float32)
+    assert rel(o, F.layer_norm(x[:13], (D,), w[0], b[0], 1e-6)) < 2e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])

@@ -14,6 +14,8 @@ run attn1 ATTN_MODE=1 pmc_attn.py
 run attn2 ATTN_MODE=2 pmc_attn.py
 run attn3 ATTN_MODE=3 pmc_attn.py
 run gemm7 GEMM_MODE=7 pmc_gemm.py
+run gemm7_fc1 "GEMM_MODE=7 GEMM_SHAPE=fc1" pmc_gemm.py
+run conv "GEMM_MODE=0 GEMM_SHAPE=conv" pmc_gemm.py
 run gemm_hipblaslt GEMM_MODE=-1 pmc_gemm.py
 python - <<'PY'
 import collections, csv, glob, json, os
