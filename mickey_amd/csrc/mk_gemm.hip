@@ -190,7 +190,7 @@ using namespace mk::gemm;
 extern "C" {
 
 int mk_gemm_set_tile(int mode) {
-  if (mode >= 400 && mode < 528) {   // dev: band height of the 256x256 tile order
+  if (mode >= 400 && mode < 464) {   // dev: band height of the 256x256 tile order
     g_band_m = mode - 400 > 0 ? mode - 400 : 1;
     return MK_OK;
   }
