@@ -4,9 +4,11 @@
 # hipBLASLt (tools/pmc_clock.sh), the GEMM shapes against hipBLASLt.  Outputs under gpurun_out/${TAG}_*; copy to profiles/.
 TAG=${TAG:-r03}
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/${TAG}_pytest_gpu.txt
-cat gpurun_out/${TAG}_pytest_gpu.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.txt
+if [ -z "$SKIP_TESTS" ]; then   # SKIP_TESTS=1: the suite and smoke() ran in a call of their own
+  timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/${TAG}_pytest_gpu.txt
+  cat gpurun_out/${TAG}_pytest_gpu.txt
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.txt
+fi
 TAG=$TAG bash tools/profile_round.sh
 bash tools/pmc_clock.sh 2>&1 | tail -50 > gpurun_out/${TAG}_pmc_clock.log
 cp gpurun_out/r03_pmc_clock.json gpurun_out/${TAG}_pmc_clock.json 2>/dev/null
