@@ -10,13 +10,20 @@ run() {  # tag, env assignment, script
   rm -rf /tmp/pc_$1
   env $2 NIMG=64 REPS=12 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pc_$1 -o p -- python $R/tools/$3 > /tmp/pc_$1.log 2>&1 || tail -3 /tmp/pc_$1.log
 }
+if [ -n "$ONLY_GEMM" ]; then   # quick pass: the GEMM shapes only
+run gemm7 GEMM_MODE=7 pmc_gemm.py
+run gemm7_long "GEMM_MODE=7 GEMM_SHAPE=long" pmc_gemm.py
+run conv "GEMM_MODE=0 GEMM_SHAPE=conv" pmc_gemm.py
+else
 run attn1 ATTN_MODE=1 pmc_attn.py
 run attn2 ATTN_MODE=2 pmc_attn.py
 run attn3 ATTN_MODE=3 pmc_attn.py
 run gemm7 GEMM_MODE=7 pmc_gemm.py
 run gemm7_fc1 "GEMM_MODE=7 GEMM_SHAPE=fc1" pmc_gemm.py
 run conv "GEMM_MODE=0 GEMM_SHAPE=conv" pmc_gemm.py
+run gemm7_long "GEMM_MODE=7 GEMM_SHAPE=long" pmc_gemm.py
 run gemm_hipblaslt GEMM_MODE=-1 pmc_gemm.py
+fi
 python - <<'PY'
 import collections, csv, glob, json, os
 out = {}

@@ -1,4 +1,4 @@
-"""One GEMM shape under rocprofv3 --pmc (dev tool): GEMM_MODE = mk_gemm_set_tile value; GEMM_SHAPE = fc2 | fc1 of 16 image pairs, or
+"""One GEMM shape under rocprofv3 --pmc (dev tool): GEMM_MODE = mk_gemm_set_tile value; GEMM_SHAPE = fc2 | fc1 | long (K = 9216, N = 512) of 16 image pairs, or
 conv = the first 3x3 convolution of the heads on the same pairs."""
 import math
 import os
@@ -27,7 +27,8 @@ if SHAPE == "conv":
         ops.conv3x3(x, C1, w, bias, out, Cout, G, nimg, H, W, act=ops.ACT_RELU, stride_in1=0, stride_w=Cout * 9 * C1,
                     stride_bias=Cout, stride_out=R * Cout, out_bordered=True)
 else:
-    M, N, K = (3878 * 16, 1024, 4096) if SHAPE == "fc2" else (3878 * 16, 4096, 1024)
+    # long: the conv's GEMM shape (K = 9216, 512 output channels) as a dense problem
+    M, N, K = {"fc2": (3878 * 16, 1024, 4096), "fc1": (3878 * 16, 4096, 1024), "long": (3876 * 16, 512, 9216)}[SHAPE]
     a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
     w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
     out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
