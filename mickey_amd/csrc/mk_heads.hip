@@ -8,7 +8,7 @@ namespace {
 using namespace mk;
 
 constexpr int KVW = 272;     // 16x16 KV + 16 Ksum per (group, image, head)
-constexpr int KV_CHUNK = 64; // tokens per partial block
+constexpr int KV_CHUNK = 64; // tokens per partial block (64 KiB of staged rows at C = 128; 32 measured the same here and doubled the reduce)
 
 template <typename T>
 __global__ __launch_bounds__(256) void posenc_kernel(const T* __restrict__ x, const float* __restrict__ pe,
@@ -34,50 +34,80 @@ __global__ __launch_bounds__(256) void posenc_kernel(const T* __restrict__ x, co
 
 __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.0f : expf(x); }  // elu(x) + 1
 
-// partial KV over a chunk of tokens for ALL heads of one (group, image): thread = (head, d, half of v); whole
-// 3C-wide rows are read coalesced (k as scalars, v as 2 x float4)
+// partial KV over a chunk of KV_CHUNK tokens for ALL heads of one (group, image) (C = 128: 8 heads of 16).
+// The chunk's k and v rows (1 KiB per token, contiguous in the 3C-wide qkv row) are staged into LDS by LDS-DMA (no register
+// round trip, everything in flight at once), phi() is applied to the k half in place (once per element), then ONE wave works on a token:
+// lane = (head, half of v, quarter of d) holds a 4 x 8 block of the head's 16 x 16 outer product, 3 LDS reads per 32 FMAs
+// -- the first version had one thread per (head, d, half of v) read k and v straight from global memory: every v float4
+// was requested by 16 lanes and every k by 2 (1 KiB of requests per 128 unique bytes), 2.4 TB/s.  The block's 4 waves take
+// every 4th token and their partial sums are combined in wave order.
 __global__ __launch_bounds__(256) void linattn_kv_partial(const float* __restrict__ qkv, float* __restrict__ part, int L, int C,
                                                           int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float skv[];   // [KV_CHUNK][2C]: phi(k) | v ; reused for the wave partials
   const int H = C >> 4;
   const long long gi = blockIdx.y;      // g*nimg + img
   const int chunk = blockIdx.x;
-  const int t = threadIdx.x;
-  const int h = t >> 5, d = (t >> 1) & 15, vh = t & 1;
-  if (h >= H) return;
-  const int s0 = chunk * KV_CHUNK, s1 = min(L, s0 + KV_CHUNK);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int s0 = chunk * KV_CHUNK, ntok = min(L, s0 + KV_CHUNK) - s0;
   const float invL = 1.0f / (float)L;
-  const float* base = qkv + gi * (long long)L * 3 * C;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float ks = 0.f;
-  // four tokens per trip: all 12 loads of a trip are in flight before the first is consumed (one token per trip left the
-  // kernel waiting on a single HBM round trip per token: 2.4 TB/s); the accumulation order over tokens is unchanged
-  const float* col = base + h * 16;
-  for (int s = s0; s < s1; s += 4) {
-    float kr[4];
-    f32x4 v0[4], v1[4];
+  const float* base = qkv + (gi * (long long)L + s0) * 3 * C + C;   // k of the chunk's first token
+  const int c4 = 2 * C / 4;                                          // float4 per token (k | v)
+  // LDS-DMA, 16 B per lane: float4 i of the staged image <- token i / c4, column 4 (i % c4); a wave instruction fills 1 KiB
+  // of LDS (one token at C = 128).  KV_CHUNK * c4 is a multiple of 256: nothing waits until all trips are issued.
+  for (int it = 0; it < KV_CHUNK * c4 / 256; ++it) {
+    const int i = it * 256 + t;
+    const int s = min(i / c4, ntok - 1), c = (i % c4) * 4;
+    glds16(base + (long long)s * 3 * C + c, (char*)skv + (it * 256 + wave * 64) * 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = t; i < ntok * (C / 4); i += 256) {   // phi() on the k half, in place, once per element
+    const int s = i / (C / 4), c = (i - s * (C / 4)) * 4;
+    f32x4 v = *(const f32x4*)(skv + s * 2 * C + c);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* row = col + (long long)min(s + u, s1 - 1) * 3 * C;
-      kr[u] = __builtin_nontemporal_load(row + C + d);
-      v0[u] = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + vh * 8));
-      v1[u] = __builtin_nontemporal_load((const f32x4*)(row + 2 * C + vh * 8 + 4));
-    }
+    for (int e = 0; e < 4; ++e) v[e] = phi(v[e]);
+    *(f32x4*)(skv + s * 2 * C + c) = v;
+  }
+  __syncthreads();
+  const int h = lane >> 3, vh = (lane >> 2) & 1, dg = lane & 3;
+  float acc[4][8];
+  float ks[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (s + u >= s1) break;
-      const float kd = phi(kr[u]);
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[e] += kd * (v0[u][e] * invL);
-        acc[4 + e] += kd * (v1[u][e] * invL);
+    for (int e = 0; e < 8; ++e) acc[a][e] = 0.f;
+  if (h < H) {
+    for (int s = wave; s < ntok; s += 4) {
+      const float* row = skv + s * 2 * C + h * 16;
+      const f32x4 k4 = *(const f32x4*)(row + dg * 4);
+      const f32x4 v0 = *(const f32x4*)(row + C + vh * 8), v1 = *(const f32x4*)(row + C + vh * 8 + 4);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[a][e] += k4[a] * (v0[e] * invL);
+          acc[a][4 + e] += k4[a] * (v1[e] * invL);
+        }
+        ks[a] += k4[a];
       }
-      ks += kd;
     }
   }
-  float* o = part + (((gi * H + h) * nchunk) + chunk) * KVW;
+  __syncthreads();   // everybody is done reading the staged rows: the buffer now takes the 4 wave partials [wave][H][KVW]
+  if (h < H) {
+    float* o = skv + (wave * H + h) * KVW;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[d * 16 + vh * 8 + e] = acc[e];
-  if (vh == 0) o[256 + d] = ks;
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[(dg * 4 + a) * 16 + vh * 8 + e] = acc[a][e];
+      if (vh == 0) o[256 + dg * 4 + a] = ks[a];
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < H * KVW; i += 256) {
+    const int hh = i / KVW, e = i - hh * KVW;
+    const float r = ((skv[(0 * H + hh) * KVW + e] + skv[(1 * H + hh) * KVW + e]) + skv[(2 * H + hh) * KVW + e]) + skv[(3 * H + hh) * KVW + e];
+    part[(((gi * H + hh) * nchunk) + chunk) * KVW + e] = r;
+  }
 }
 
 __global__ __launch_bounds__(KVW) void linattn_kv_reduce(const float* __restrict__ part, float* __restrict__ kv, int nchunk) {
@@ -268,7 +298,9 @@ int mk_linattn_kv(const float* qkv, float* kv, float* work, int groups, int nimg
   MK_CHECK_ARG(qkv && kv && work && groups > 0 && nimg > 0 && L > 0 && C % 16 == 0 && C <= 128, "mk_linattn_kv: bad args (C <= 128)");
   const int nchunk = (L + KV_CHUNK - 1) / KV_CHUNK;
   const int gih = groups * nimg * (C / 16);
-  hipLaunchKernelGGL(linattn_kv_partial, dim3(nchunk, groups * nimg), dim3(256), 0, (hipStream_t)stream, qkv, work, L, C,
+  size_t lds = (size_t)KV_CHUNK * 2 * C * sizeof(float);         // the staged rows, then reused for
+  if (lds < (size_t)4 * (C / 16) * KVW * sizeof(float)) lds = (size_t)4 * (C / 16) * KVW * sizeof(float);   // the 4 wave partials
+  hipLaunchKernelGGL(linattn_kv_partial, dim3(nchunk, groups * nimg), dim3(256), lds, (hipStream_t)stream, qkv, work, L, C,
                      nchunk);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(linattn_kv_reduce, dim3(gih), dim3(KVW), 0, (hipStream_t)stream, work, kv, nchunk);
