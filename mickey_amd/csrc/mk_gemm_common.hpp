@@ -804,11 +804,11 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 // with the plain ones).  0 = the plain epilogues, 1 = folded-LayerNorm consumer (QKV / bias (+GELU) with row parameters),
 // 2 = folded-LayerNorm producer (split residual stream), 3 = the same writing fp32 rows (last block): 2 and 3 together in
 // one kernel spill again.
-template <typename T, int KIND, bool CONV = false>
+template <typename T, int KIND, bool CONV = false, int BN = 256>
 __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
                                              int lane, int g, const float2* lnp = nullptr) {
   if constexpr (KIND == 2 || KIND == 3) {
-    const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;   // workgroup-uniform
+    const bool interior = m0 + 256 <= p.M && n0 + BN <= p.N;   // workgroup-uniform
     if (KIND == 3) {   // LS_RESIDUAL with fp32 rows out (last block)
       if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
@@ -860,6 +860,7 @@ __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_
 int num_cus();
 // schedule launchers (one translation unit each); amode = A_DENSE | A_CONV3, dtype = MK_BF16 | MK_F16
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
+int launch_t2(const GemmParams& p, int groups, int dtype, hipStream_t st, int band_m);   // 256x128, two workgroups per CU (dense only)
 int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)
 
 }  // namespace gemm

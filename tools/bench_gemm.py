@@ -15,9 +15,11 @@ from tools.bench_kernels import timeit  # noqa: E402
 
 modes = [int(t) for t in sys.argv[1:]] or [7, -1]
 dev = torch.device("cuda:0")
-nimg, ntok, pad, heads = 64, 1939, 1984, 16
+# NIMG images (64 = the bench batch, 2 = one pair) of WIDTH-wide tokens (1024 = ViT-L, 384 = ViT-S)
+nimg, D = int(os.environ.get("NIMG", "64")), int(os.environ.get("WIDTH", "1024"))
+ntok, pad, heads = 1939, 1984, D // 64
 M = nimg * ntok
-for (N, K, name) in ((3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc1"), (1024, 4096, "fc2")):
+for (N, K, name) in ((3 * D, D, "qkv"), (D, D, "proj"), (4 * D, D, "fc1"), (D, 4 * D, "fc2")):
     a = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
     w = (torch.randn((N, K), device=dev) / math.sqrt(K)).bfloat16()
     bias = torch.randn((N,), device=dev)
@@ -49,7 +51,7 @@ for (N, K, name) in ((3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc
             ts[(m, 1)].append(timeit(fused, iters=10, warm=2))
     ops.gemm_set_tile(0)
     fl = 2.0 * M * N * K
-    line = "M=%6d %-4s " % (M, name)
+    line = "M=%6d D=%4d %-4s " % (M, D, name)
     for m in modes:
         line += " | %s bare %6.1f" % ("hipBLASLt" if m < 0 else "mode%d" % m, fl / statistics.median(ts[(m, 0)]) / 1e12)
         if m >= 0:
