@@ -13,7 +13,7 @@ extern "C" {
 /* Schedule of the GEMM / implicit-GEMM conv kernel: 0 = automatic (128x128 tiles for small problems, the default
  * 256x256 schedule for large ones; 64x128 tiles where 128x128 would leave CUs idle), 1 = force 128x128 (4 waves, 2
  * workgroups per CU), 2 = force 64x128 (same kernel, half the rows, 3 workgroups per CU), 7 = force the 8-wave ping-pong
- * 256x256 schedule (two waves per SIMD), 8 = force the 256x128 schedule with two 4-wave workgroups per CU (dense only);
+ * 256x256 schedule (two waves per SIMD);
  * 400 + b sets the band height b (in m-tiles) of the 256x256 tile order; 500 / 501 switch the automatic use of the 64x128
  * tiling off / on. */
 int mk_gemm_set_tile(int mode);

@@ -128,7 +128,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
 int g_num_cus = 0;
 int g_band_m = 8;      // m-tiles per band of the 256x256 tile order (dev: mk_gemm_set_tile 400 + b)
 int g_half_rows = 1;   // automatic choice may use the 64x128 tiling for under-filled launches (dev: 500 off / 501 on)
-int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong, 8 force 256x128 (two per CU)
+int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong
 
 template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
@@ -151,9 +151,6 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   if (sched == 0) sched = (big && k_ok) ? 7 : 1;
   if (!k_ok) sched = 1;
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
-  if (sched == 8 && AMODE == A_DENSE && p.N >= 128 && p.K >= 2 * 32 && (long long)p.M * p.lda < (1ll << 31) &&
-      (long long)p.N * p.ldw < (1ll << 31))
-    return launch_t2(p, groups, dtype, st, g_band_m);
   // 128x128 tiles fill a 256-CU part (2 workgroups per CU) from 512 tiles on; below that 64-row tiles double the count
   const long long small_tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * groups;
   const bool half_rows = g_schedule == 2 || (g_schedule != 1 && g_half_rows && small_tiles < 2 * num_cus() && p.M > 64);
@@ -201,8 +198,8 @@ int mk_gemm_set_tile(int mode) {
     g_half_rows = mode - 500;
     return MK_OK;
   }
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7 || mode == 8,
-               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong, 8 256x128 two per CU)", mode);
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7,
+               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong)", mode);
   g_schedule = mode;
   return MK_OK;
 }

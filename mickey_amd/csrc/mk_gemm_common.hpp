@@ -860,7 +860,6 @@ __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_
 int num_cus();
 // schedule launchers (one translation unit each); amode = A_DENSE | A_CONV3, dtype = MK_BF16 | MK_F16
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
-int launch_t2(const GemmParams& p, int groups, int dtype, hipStream_t st, int band_m);   // 256x128, two workgroups per CU (dense only)
 int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)
 
 }  // namespace gemm

@@ -34,7 +34,7 @@ def _auto_tile():
         ops.attn_set_mode(0)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])
 def test_gemm_bias_act(dtype, M, N, K, tile):
@@ -60,7 +60,7 @@ def test_gemm_bias_act(dtype, M, N, K, tile):
     assert torch.equal(out.cpu(), w.float()[:, :64].t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 4096), (700, 384, 256)])
 def test_gemm_ls_residual(M, N, K, tile):
     from mickey_amd import ops
@@ -76,7 +76,7 @@ def test_gemm_ls_residual(M, N, K, tile):
     assert rel(xd, ref) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 def test_gemm_qkv_layout(tile):
     from mickey_amd import ops
     dev = _dev()
@@ -101,7 +101,7 @@ def test_gemm_qkv_layout(tile):
     assert float(q[:, :, ntok:].abs().sum()) == 0.0  # pad rows untouched
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8])
+@pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("nimg,H,W,D", [(2, 75, 101, 256), (3, 300, 290, 384)])   # 5 x 7 and 21 x 20 patches
 def test_patch_embed_and_cls(nimg, H, W, D, tile):
     from mickey_amd import ops
@@ -139,7 +139,7 @@ def _split(x, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [1, 2, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 256), (700, 384, 128), (257, 128, 64)])
 def test_ln_fold_producer_residual(M, N, K, tile, dtype):
     """mk_gemm_ls_residual_ln on the split residual stream (x = hi + lo): the new fp32 rows are what mk_gemm_ls_residual
@@ -183,7 +183,7 @@ def test_ln_fold_producer_residual(M, N, K, tile, dtype):
     assert torch.equal(x_out, x_ref) and torch.equal(hi2, hi0) and torch.equal(lo2, lo0) and float(st2.abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [0, 7, 8])
+@pytest.mark.parametrize("tile", [0, 7])
 @pytest.mark.parametrize("nimg,H,W,D", [(2, 75, 101, 256), (3, 300, 290, 384)])
 def test_ln_fold_producer_patch_embed_and_cls(nimg, H, W, D, tile):
     from mickey_amd import ops
@@ -236,7 +236,7 @@ def _ln_fold_inputs(M, D, N, dtype, dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [1, 2, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("M,D,N,act", [(3878, 1024, 1024, 2), (700, 384, 512, 0), (130, 128, 256, 2)])
 def test_ln_fold_consumer_gemm(M, D, N, act, tile, dtype):
     """mk_gemm_ln == act(LayerNorm(x) @ W^T + b) with the normalisation applied in the epilogue: exact (fp32 accumulation)
@@ -270,7 +270,7 @@ def _dino_like_rows(M, D, level, gen):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [1, 7, 8])
+@pytest.mark.parametrize("tile", [1, 7])
 @pytest.mark.parametrize("level", [0.0, 3.0, 30.0])
 def test_ln_fold_row_centring_chain(level, tile, dtype):
     """The folded LayerNorm on rows with a common-mode level of 0 / 3 / 30 sigma and massive-activation channels
@@ -344,7 +344,7 @@ def test_recentre_split(D, dtype):
     assert bool(torch.isfinite(st).all())
 
 
-@pytest.mark.parametrize("tile", [1, 7, 8])
+@pytest.mark.parametrize("tile", [1, 7])
 def test_ln_fold_consumer_qkv(tile):
     from mickey_amd import ops
     dev = _dev()
