@@ -20,7 +20,7 @@ int mk_gemm_set_tile(int mode);
 
 /* Kernel variant of mk_flash_attn_fwd: 0 = automatic (2 for >= 512 workgroups of 256 queries, 1 for smaller grids),
  * 1 / 2 = the production kernel with 32 / 64 queries per wave (lean softmax: running maximum folded into the MFMA
- * accumulator init, re-based only when a tile exceeds it by 2^8; fp32 row sums on the VALU), 3 = the classic online-softmax
+ * accumulator init, re-based only when a tile outgrows it, seen in the row sums; fp32 row sums on the VALU), 3 = the classic online-softmax
  * kernel (64 queries per wave; A/B partner).  Process-wide; for benchmarks and tests. */
 int mk_attn_set_mode(int mode);
 

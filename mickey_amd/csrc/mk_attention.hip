@@ -5,7 +5,7 @@
 // Design (wave64, v_mfma_f32_32x32x16):
 //  * workgroup = 4 waves of one (image, head); each wave owns 32 or 64 queries (QB sub-blocks of 32).
 //  * two kernels share this design (mk_attn_set_mode): attn_fwd_fold_kernel (production: the lean softmax -- running maximum
-//    folded into the accumulator init, re-based only when a tile exceeds it by 2^8 -- with fp32 row sums on the VALU) and
+//    folded into the accumulator init, re-based only when a tile outgrows it, detected from the row sums -- with fp32 row sums on the VALU) and
 //    attn_fwd_kernel (classic online softmax, kept as the A/B partner).  Round 3 built and measured three more structures
 //    (one wave per SIMD with an asm-owned accumulator file, ping-pong wave-rows, matrix-pipe row sums): DESIGN.md 2.2.
 //  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
@@ -30,7 +30,7 @@ namespace {
 using namespace mk;
 
 constexpr int KV_TILE_BYTES = 64 * 64 * 2;  // 8 KiB
-constexpr float ATT_REBASE_THR = 8.0f;    // lean softmax: the running maximum is re-based when a tile exceeds it by 2^8
+constexpr float ATT_REBASE_SUM = 4096.0f; // lean softmax: the running maximum is re-based when a lane's share of a tile's row sum exceeds 2^12
 
 // XCD-aware decode of the workgroup id.  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so
 // with the natural (query block, head, image) grid the 16 query blocks of one (image, head) land on all 8 XCDs and every
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 // attention kernel (and the GEMM) at its power limit -- profiles/r03_pmc_clock_attention_variants.json: variants that need fewer
 // cycles run at a lower clock and finish at the same wall time -- so the kernel that issues the least work wins:
 //   * no subtraction of the running maximum (folded into the MFMA accumulator init), no per-tile rescale of O (re-base only
-//     when a tile exceeds the maximum by 2^8), 16 MFMAs per 32 x 64 tile (the matrix-pipe row sums of the lean kernel were a
+//     when a lane's share of a row sum exceeds 2^12: no per-tile maximum at all), 16 MFMAs per 32 x 64 tile (the matrix-pipe row sums of the lean kernel were a
 //     fifth of its matrix work: 805-825 -> 885 TFLOP/s when they went back to 32 fp32 adds);
 //   * QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and a workgroup covers 256 queries per staged tile.
 template <typename T, int QB>
@@ -312,14 +312,38 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
             if (key >= ntok) s[qb][kb][r] = -1e30f;
           }
       }
-      float t8[8];
+      // P = 2^S' and this lane's share of the row sums.  No maximum is taken on the way (32 scores cost ~20 v_max, as many VALU
+      // issues as their conversion to 16 bit): a score that outgrew the running maximum shows in the SUM -- any P > 2^12
+      // makes its lane's sum > 2^12 -- and only then (wave-uniform, after the first tile practically never) is the maximum
+      // computed and m re-based; S' is still in registers, nothing is recomputed on the matrix pipe.  2^12 keeps P inside
+      // fp16 and the sums far from overflow; softmax is invariant to where m sits, fp32 sums are relative to their largest term.
+      auto exp_sum = [&]() {
+        float rs4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 32-deep dependent add chain
 #pragma unroll
-      for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s[qb][0][r], s[qb][0][r + 8]), fmaxf(s[qb][1][r], s[qb][1][r + 8]));
-      float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
-      mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
-      if (__any(mx > ATT_REBASE_THR) || first) {   // wave-uniform, rare after the first tile: re-base m to this tile's maximum
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(s[qb][s4 >> 1][(s4 & 1) * 8 + e]);
+            pf[qb][s4][e] = (T)pv;
+            rs4[e & 3] += pv;
+          }
+        return (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+      };
+      float rs = 0.f;
+      bool rebase = first;
+      if (!first) {
+        rs = exp_sum();
+        rebase = __any(!(rs <= ATT_REBASE_SUM));   // also true for inf / nan
+      }
+      if (rebase) {   // the first tile, and tiles that outgrew m: re-base m to this tile's maximum
+        float t8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t8[r] = fmaxf(fmaxf(s[qb][0][r], s[qb][0][r + 8]), fmaxf(s[qb][1][r], s[qb][1][r + 8]));
+        float mx = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), t8[2]), fmaxf(fmaxf(t8[3], t8[4]), t8[5]));
+        mx = fmaxf(fmaxf(mx, t8[6]), t8[7]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile
+        const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile (rows that did not outgrow
+                                                             // it: shift 0, bit-identical to not re-basing)
         const float alpha = __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -332,17 +356,9 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
         m_run[qb] += shift;
 #pragma unroll
         for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
+        rs = exp_sum();
       }
-      float rs4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 32-deep dependent add chain
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(s[qb][s4 >> 1][(s4 & 1) * 8 + e]);
-          pf[qb][s4][e] = (T)pv;
-          rs4[e & 3] += pv;
-        }
-      l_run[qb] += (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+      l_run[qb] += rs;
     }
     first = false;
 #pragma unroll
