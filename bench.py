@@ -170,6 +170,9 @@ class StageProfiler:
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
                 ent.update(achieved=ach, peak=PEAK_MFMA_TF, unit="TFLOP/s", frac=ach / PEAK_MFMA_TF,
                            algorithmic_gflop_per_step=d["work"] / steps / 1e9)
+                if d["bytes"] > 0:   # the same launches against the OTHER roof (narrow models: K = 384 linears are as much HBM as MFMA)
+                    ent.update(algorithmic_mb_per_step=d["bytes"] / steps / 1e6,
+                               hbm_frac=d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS)
             elif bound == "hbm":
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e9
                 ent.update(achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
