@@ -563,7 +563,8 @@ def main(argv=None):
                "finite_output": bool(torch.isfinite(lastl["R"]).all())}
         if prof is not None and prof.records and not len(m._graphs):
             st, _ = prof.summary(steps)
-            ent["stages"] = [{k: s[k] for k in ("stage", "bound", "ms_per_step", "achieved", "peak", "unit", "frac") if k in s} for s in st]
+            ent["stages"] = [{k: s[k] for k in ("stage", "bound", "ms_per_step", "achieved", "peak", "unit", "frac", "hbm_frac") if k in s}
+                             for s in st]
             dom = [s for s in st if s["stage"] == dominant]
             if dom:
                 ent["roofline"] = {k: dom[0][k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac")}
