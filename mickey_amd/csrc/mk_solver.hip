@@ -585,7 +585,7 @@ __device__ __forceinline__ float pt_dist(const float* R, const float* t, const f
   return sqrtf(s + 1e-6f);
 }
 
-// ---- hypotheses: block = (set r, slice of its hypotheses); wave = hypothesis -------------------------
+// ---- hypotheses: block = (set r, slice of its hypotheses); wave = a few hypotheses, their SVDs one per lane ---
 __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                          const float* __restrict__ wts, const float* __restrict__ noise3,
                                                          const int* __restrict__ idx3_in, unsigned k0, unsigned k1,
@@ -610,83 +610,117 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
   const int per = (it_ransac + nsplit - 1) / nsplit;
   const int h0 = part * per, h1 = min(it_ransac, h0 + per);
   const float beta = 5.0f / th_soft;
-  for (int h = h0 + wave; h < h1; h += 4) {
-    const long long hyp = (long long)r * it_ransac + h;
-    int sel[3];
-    if (idx3_in) {
-      sel[0] = idx3_in[hyp * 3 + 0];
-      sel[1] = idx3_in[hyp * 3 + 1];
-      sel[2] = idx3_in[hyp * 3 + 2];
-    } else {
-      // per-lane top-3 of key = w / e, then 3 wave arg-max rounds
-      float bk[3] = {-1.f, -1.f, -1.f};
-      int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-      for (int base = lane * 4; base < k; base += 256) {
-        float e[4];
-        if (noise3) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) e[q] = base + q < k ? noise3[hyp * k + base + q] : 1.f;
-        } else {
-          const long long gh = hyp + set_base * it_ransac;   // GLOBAL hypothesis index: draws do not depend on how a batch is split
-          const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(base >> 2), (unsigned)gh, (unsigned)(gh >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
-          e[0] = exp1(rnd.x); e[1] = exp1(rnd.y); e[2] = exp1(rnd.z); e[3] = exp1(rnd.w);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = base + q;
-          if (j >= k) continue;
-          const float key = sW[j] / e[q];
-          if (key > bk[2]) {  // strict: earlier (lower) index wins ties
-            if (key > bk[0]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = bk[0]; bi[1] = bi[0]; bk[0] = key; bi[0] = j; }
-            else if (key > bk[1]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = key; bi[1] = j; }
-            else { bk[2] = key; bi[2] = j; }
+  // A wave owns the hypotheses h0 + wave, + 4, ...  Three phases per pass of up to HYP_PASS of them:
+  //   1. selection (wave-cooperative arg-max over the k matches) and the 3 x 3 cross-covariance, parked in lane i;
+  //   2. the fp64 Jacobi SVD of ALL parked hypotheses at once, one per lane (computed redundantly by 64 lanes it was most of
+  //      this kernel's time: divisions and square roots in fp64 at a fraction of the fp32 rate, hypothesis after hypothesis);
+  //   3. soft-inlier scoring, wave-cooperative again, R and t broadcast from lane i.
+  // Every hypothesis sees exactly the arithmetic it saw before: the results are bit-identical.
+  constexpr int HYP_PASS = 8;
+  for (int hb = h0 + wave; hb < h1; hb += 4 * HYP_PASS) {
+    double myH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float myam[3] = {0.f, 0.f, 0.f}, mybm[3] = {0.f, 0.f, 0.f};
+    int mysel[3] = {0, 0, 0};
+    for (int i = 0; i < HYP_PASS; ++i) {
+      const int h = hb + 4 * i;
+      if (h >= h1) break;
+      const long long hyp = (long long)r * it_ransac + h;
+      int sel[3];
+      if (idx3_in) {
+        sel[0] = idx3_in[hyp * 3 + 0];
+        sel[1] = idx3_in[hyp * 3 + 1];
+        sel[2] = idx3_in[hyp * 3 + 2];
+      } else {
+        // per-lane top-3 of key = w / e, then 3 wave arg-max rounds
+        float bk[3] = {-1.f, -1.f, -1.f};
+        int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int base = lane * 4; base < k; base += 256) {
+          float e[4];
+          if (noise3) {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = base + q < k ? noise3[hyp * k + base + q] : 1.f;
+          } else {
+            const long long gh = hyp + set_base * it_ransac;   // GLOBAL hypothesis index: draws do not depend on how a batch is split
+            const U4 rnd = philox4x32(k0, k1, U4{(unsigned)(base >> 2), (unsigned)gh, (unsigned)(gh >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
+            e[0] = exp1(rnd.x); e[1] = exp1(rnd.y); e[2] = exp1(rnd.z); e[3] = exp1(rnd.w);
+          }
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = base + q;
+            if (j >= k) continue;
+            const float key = sW[j] / e[q];
+            if (key > bk[2]) {  // strict: earlier (lower) index wins ties
+              if (key > bk[0]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = bk[0]; bi[1] = bi[0]; bk[0] = key; bi[0] = j; }
+              else if (key > bk[1]) { bk[2] = bk[1]; bi[2] = bi[1]; bk[1] = key; bi[1] = j; }
+              else { bk[2] = key; bi[2] = j; }
+            }
           }
         }
-      }
-#pragma unroll
-      for (int round = 0; round < 3; ++round) {
-        float v = bk[0];
-        int ix = bi[0];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float v2 = __shfl_xor(v, o, 64);
-          const int i2 = __shfl_xor(ix, o, 64);
-          if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+  #pragma unroll
+        for (int round = 0; round < 3; ++round) {
+          float v = bk[0];
+          int ix = bi[0];
+  #pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(v, o, 64);
+            const int i2 = __shfl_xor(ix, o, 64);
+            if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+          }
+          sel[round] = ix;
+          if (bi[0] == ix) { bk[0] = bk[1]; bi[0] = bi[1]; bk[1] = bk[2]; bi[1] = bi[2]; bk[2] = -1.f; bi[2] = 0x7fffffff; }
         }
-        sel[round] = ix;
-        if (bi[0] == ix) { bk[0] = bk[1]; bi[0] = bi[1]; bk[1] = bk[2]; bi[1] = bi[2]; bk[2] = -1.f; bi[2] = 0x7fffffff; }
+      }
+      // means and cross-covariance of the 3 pairs (reference loss/solvers.py:31-39,45-52)
+      float am[3], bm[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        am[a] = (sX[sel[0] * 3 + a] + sX[sel[1] * 3 + a] + sX[sel[2] * 3 + a]) / 3.0f;
+        bm[a] = (sY[sel[0] * 3 + a] + sY[sel[1] * 3 + a] + sY[sel[2] * 3 + a]) / 3.0f;
+      }
+      const bool mine = lane == i;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float sm = 0.f;
+#pragma unroll
+          for (int pnt = 0; pnt < 3; ++pnt) sm += (sX[sel[pnt] * 3 + a] - am[a]) * (sY[sel[pnt] * 3 + c] - bm[c]);
+          if (mine) myH[a * 3 + c] = (double)sm;
+        }
+        if (mine) {
+          myam[a] = am[a];
+          mybm[a] = bm[a];
+          mysel[a] = sel[a];
+        }
       }
     }
-    // Kabsch on the 3 pairs, computed redundantly by every lane (reference loss/solvers.py:31-39,45-52)
-    float am[3], bm[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      am[a] = (sX[sel[0] * 3 + a] + sX[sel[1] * 3 + a] + sX[sel[2] * 3 + a]) / 3.0f;
-      bm[a] = (sY[sel[0] * 3 + a] + sY[sel[1] * 3 + a] + sY[sel[2] * 3 + a]) / 3.0f;
-    }
-    double H[9];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float s = 0.f;
-#pragma unroll
-        for (int pnt = 0; pnt < 3; ++pnt) s += (sX[sel[pnt] * 3 + a] - am[a]) * (sY[sel[pnt] * 3 + c] - bm[c]);
-        H[a * 3 + c] = (double)s;
-      }
     double Rd[9];
-    kabsch_rotation(H, Rd);
-    float Rf[9], tf[3];
+    kabsch_rotation(myH, Rd);
+    float myR[9], myt[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+    for (int q = 0; q < 9; ++q) myR[q] = (float)Rd[q];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) tf[a] = bm[a] - (am[0] * Rf[a * 3 + 0] + am[1] * Rf[a * 3 + 1] + am[2] * Rf[a * 3 + 2]);
-    float sc = 0.f;
-    for (int j = lane; j < k; j += 64) sc += sigmoidf(beta * (th_soft - pt_dist(Rf, tf, sX + j * 3, sY + j * 3)));
-    sc = wave_sum(sc);
-    if (lane < 9) Rh[hyp * 9 + lane] = Rf[lane];
-    if (lane < 3) { th[hyp * 3 + lane] = tf[lane]; idx3[hyp * 3 + lane] = sel[lane]; }
-    if (lane == 0) score[hyp] = sc;
+    for (int a = 0; a < 3; ++a) myt[a] = mybm[a] - (myam[0] * myR[a * 3 + 0] + myam[1] * myR[a * 3 + 1] + myam[2] * myR[a * 3 + 2]);
+    for (int i = 0; i < HYP_PASS; ++i) {
+      const int h = hb + 4 * i;
+      if (h >= h1) break;
+      const long long hyp = (long long)r * it_ransac + h;
+      float Rf[9], tf[3];
+      int sel[3];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Rf[q] = __shfl(myR[q], i, 64);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        tf[a] = __shfl(myt[a], i, 64);
+        sel[a] = __shfl(mysel[a], i, 64);
+      }
+      float sc = 0.f;
+      for (int jj = lane; jj < k; jj += 64) sc += sigmoidf(beta * (th_soft - pt_dist(Rf, tf, sX + jj * 3, sY + jj * 3)));
+      sc = wave_sum(sc);
+      if (lane < 9) Rh[hyp * 9 + lane] = Rf[lane];
+      if (lane < 3) { th[hyp * 3 + lane] = tf[lane]; idx3[hyp * 3 + lane] = sel[lane]; }
+      if (lane == 0) score[hyp] = sc;
+    }
   }
 }
 
