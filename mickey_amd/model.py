@@ -224,11 +224,13 @@ class MickeyRelativePose(nn.Module):
         im1 = data["image1"].to(device=dev, dtype=torch.float32)
         B = im0.shape[0]
         same = im0.shape == im1.shape
-        imgs = [torch.cat([im0, im1], 0)] if same else [im0, im1]   # one 2B-image pass when shapes agree
+        # one 2B-image pass when shapes agree (the two image sets are patched into one token matrix: no copy of the images)
+        im0, im1 = (t if t.stride(3) == 1 else t.contiguous() for t in (im0, im1))   # the patch kernel takes any outer strides
+        imgs = [(im0, im1)] if same else [(im0,), (im1,)]
         outs = []
         for im in imgs:
-            feat, gh, gw = pipeline.encoder_forward(W, self._ws, im.contiguous())
-            scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, im.shape[0], gh, gw, self.cfg)
+            feat, gh, gw = pipeline.encoder_forward(W, self._ws, im)
+            scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, sum(t.shape[0] for t in im), gh, gw, self.cfg)
             outs.append((scr, kps, depth, dsc, gh, gw))
         if same:
             scr, kps, depth, dsc, gh, gw = outs[0]

@@ -114,11 +114,13 @@ def gemm_qkv_ln(a, w, bias, colsum, stats, eps, q, k, vt, nimg, ntok, ntok_pad, 
          ptr(shift_out), ptr(q), ptr(k), ptr(vt), nimg, ntok, ntok_pad, heads, qscale, dtype_code(a.dtype), stream())
 
 
-def im2col_patch14(img, gh, gw, ldo, dtype):
-    """img fp32 [nimg, 3, H, W] (any strides with unit innermost) -> [nimg*gh*gw, ldo] lp."""
+def im2col_patch14(img, gh, gw, ldo, dtype, out=None):
+    """img fp32 [nimg, 3, H, W] (any strides with unit innermost) -> [nimg*gh*gw, ldo] lp (out: rows to write into)."""
     assert img.dtype == torch.float32 and img.stride(3) == 1
     nimg = img.shape[0]
-    out = torch.empty((nimg * gh * gw, ldo), device=img.device, dtype=dtype)
+    if out is None:
+        out = torch.empty((nimg * gh * gw, ldo), device=img.device, dtype=dtype)
+    assert out.shape == (nimg * gh * gw, ldo) and out.dtype == dtype and out.is_contiguous()
     call("mk_im2col_patch14", ptr(img), img.stride(0), img.stride(1), img.stride(2), nimg, gh, gw, ptr(out), ldo,
          dtype_code(dtype), stream())
     return out

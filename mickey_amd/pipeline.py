@@ -29,16 +29,26 @@ class Workspace:
 
 def encoder_forward(W, ws, img):
     """img fp32 [nimg, 3, H, W] on device (already cropped view or not: the /14 crop is implicit in
-    gh, gw).  Returns the final-norm patch tokens, lp [nimg*gh*gw, D] (NHWC feature map)."""
+    gh, gw), or a sequence of such tensors of one H x W (the two image sets of a pair batch: patched straight into one
+    token matrix, no concatenated copy of the images).  Returns the final-norm patch tokens, lp, as a bordered feature map
+    of nimg gh x gw grids."""
+    imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+    img = imgs[0]
     dev, lp = img.device, W.lp
-    nimg, _, H, Wd = img.shape
+    _, _, H, Wd = img.shape
+    assert all(t.shape[1:] == img.shape[1:] for t in imgs)
+    nimg = sum(t.shape[0] for t in imgs)
     gh, gw = H // 14, Wd // 14
     npatch, D, heads = gh * gw, W.D, W.heads
     ntok = npatch + 1
     pad = (ntok + 63) // 64 * 64
     M = nimg * ntok
     pos = wts_mod.interp_pos_embed(W, gh, gw, dev)
-    a = ops.im2col_patch14(img, gh, gw, wts_mod.PATCH_K, lp)
+    a = ws.get("im2col", (nimg * npatch, wts_mod.PATCH_K), lp, dev)
+    r0 = 0
+    for t in imgs:
+        ops.im2col_patch14(t, gh, gw, wts_mod.PATCH_K, lp, out=a[r0:r0 + t.shape[0] * npatch])
+        r0 += t.shape[0] * npatch
     x = ws.get("x", (M, D), torch.float32, dev)
     att = ws.get("att", (M, D), lp, dev)
     hid = ws.get("hid", (M, 4 * D), lp, dev)

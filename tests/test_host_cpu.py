@@ -207,9 +207,9 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
             return ret(*a, **k) if callable(ret) else ret
         return f
 
-    def im2col(img, gh, gw, ldo, dtype):
+    def im2col(img, gh, gw, ldo, dtype, out=None):
         calls.append(("im2col", (), {}))
-        return torch.zeros((img.shape[0] * gh * gw, ldo), dtype=dtype)
+        return out if out is not None else torch.zeros((img.shape[0] * gh * gw, ldo), dtype=dtype)
 
     for nm in ("gemm_patch_embed", "cls_token", "gemm_qkv", "flash_attn", "gemm_ls_residual", "gemm", "gemm_patch_embed_ln",
                "cls_token_ln", "gemm_qkv_ln", "gemm_ls_residual_ln", "gemm_ln", "recentre_split"):
