@@ -167,19 +167,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // and 9 full-rate ops per element (no reciprocal, no select); written on 4-vectors so the Horner chain can use
 // v_pk_fma_f32.  The GELU runs un-overlapped in the fc1 epilogue: libm erff cost +30 % of that GEMM, the previous
 // Abramowitz-Stegun 7.1.26 form (rcp + exp + 20 ops) +20 %.
+// The Horner chain runs on v_pk_fma_f32 (two elements per issue).  Left to itself hipcc emits one v_fmaak_f32 per element and
+// step instead (a 32-bit literal is cheaper to materialise than a register pair, and VOP3P takes no literals): the
+// coefficients are therefore pinned into SGPR pairs (one scalar operand per packed FMA is allowed), once per call site.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 sgpr_pair(float c) {
+  f32x2 v = {c, c};
+  asm("" : "+s"(v));   // not volatile: identical pins of the unrolled call sites merge
+  return v;
+}
 __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
-  f32x4 u, q, r;
+  const f32x2 c6 = sgpr_pair(-3.19620214e-05f), c5 = sgpr_pair(0.000758801579f), c4 = sgpr_pair(-0.00804438837f),
+              c3 = sgpr_pair(0.0533519151f), c2 = sgpr_pair(0.45881945f), c1 = sgpr_pair(1.15118468f), c0 = sgpr_pair(0.999994836f);
+  f32x4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) u[e] = fminf(fabsf(v[e]), 6.0f);
-  q = f32x4{-3.19620214e-05f, -3.19620214e-05f, -3.19620214e-05f, -3.19620214e-05f};
-  q = q * u + 0.000758801579f;
-  q = q * u + -0.00804438837f;
-  q = q * u + 0.0533519151f;
-  q = q * u + 0.45881945f;
-  q = q * u + 1.15118468f;
-  q = q * u + 0.999994836f;
+  for (int h = 0; h < 2; ++h) {
+    f32x2 u = {fminf(fabsf(v[2 * h]), 6.0f), fminf(fabsf(v[2 * h + 1]), 6.0f)};
+    f32x2 q = __builtin_elementwise_fma(c6, u, c5);
+    q = __builtin_elementwise_fma(q, u, c4);
+    q = __builtin_elementwise_fma(q, u, c3);
+    q = __builtin_elementwise_fma(q, u, c2);
+    q = __builtin_elementwise_fma(q, u, c1);
+    q = __builtin_elementwise_fma(q, u, c0);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = fmaxf(v[e], 0.f) - fabsf(v[e]) * __builtin_amdgcn_exp2f(-q[e]);
+    for (int e = 0; e < 2; ++e) r[2 * h + e] = fmaxf(v[2 * h + e], 0.f) - fabsf(v[2 * h + e]) * __builtin_amdgcn_exp2f(-q[e]);
+  }
   return r;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf4(f32x4{x, x, x, x})[0]; }
