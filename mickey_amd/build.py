@@ -30,6 +30,7 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fno-trapping-math", "-fno-slp-vectorize"] +
                (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []) +
                (["-DMK_ATTN_LP_DBG"] if os.environ.get("MK_ATTN_LP_DBG") else []),
+               "mk_input.hip": ["-ffp-contract=off"],   # cv2-exact coordinates: (d + 0.5) * scale - 0.5 must not become an fma
                "mk_gemm_pp64.hip": (["-DMK_LN_ABL=%s" % os.environ["MK_LN_ABL"]] if os.environ.get("MK_LN_ABL") else []),
                "mk_gemm.hip": (["-DMK_PP64_ABLATIONS"] if os.environ.get("MK_PP64_ABLATIONS") else []) +
                               (["-DMK_GEMM_ABLATIONS"] if os.environ.get("MK_GEMM_ABLATIONS") else [])}

@@ -461,7 +461,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int e = 0; e < 4; ++e) dst[(long long)e * p.ntok_pad] = to_lp<T>(v[e]);
         } else {
-          if (which == 0) v *= p.qscale;
+          if (which == 0) { const float qs = p.qscale; _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= qs; }
           V4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
@@ -592,7 +592,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         if (LN) v = v * prm[mi].x + (cs[ni] * prm[mi].y + bv[ni]);
         else if (HAS_BIAS) v += bv[ni];
         if (EPI == MK_EPI_QKV) {
-          if (which == 0) v *= p.qscale;
+          if (which == 0) { const float qs = p.qscale; _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= qs; }
         } else {
           if (CONV && p.resid_lp) {
             const int m = mw + r, n = nw + fg * 4 + ni * 16;

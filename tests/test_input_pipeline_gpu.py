@@ -26,19 +26,27 @@ def test_identity_resize_is_bit_exact_with_the_reference_expression():
     assert out.shape == (5, 3, 720, 540) and torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("src,dst", [((480, 640), (720, 540)), ((1080, 1920), (360, 640)), ((33, 47), (91, 13)), ((720, 540), (719, 541))])
-def test_bilinear_resize_vs_oracle(src, dst):
+@pytest.mark.parametrize("src,dst", [((480, 640), (720, 540)), ((1080, 1920), (360, 640)), ((33, 47), (91, 13)), ((720, 540), (719, 541)),
+                                     ((1440, 1080), (720, 540)), ((720, 1080), (720, 540)), ((2, 2), (3, 3)), ((1, 2), (2, 4)),
+                                     ((256, 192), (720, 540))])
+def test_resize_is_byte_exact_with_the_cv2_algorithm(src, dst):
+    """Non-identity sizes: the kernel == oracle/input_oracle.py (cv2.resize INTER_LINEAR on uint8 as OpenCV 4.8.0 computes it:
+    11-bit fixed-point weights, two truncating products, +2 >> 2; exact 2 x 2 decimation = the fast area path; then
+    float / 255), byte for byte -- torch.equal on the fp32 result, i.e. on byte / 255.  Up- and down-scales, one axis halved
+    only (NOT the area path), degenerate 1- and 2-pixel frames (clipped rows keep their weights)."""
     from mickey_amd import ops
     from oracle import input_oracle as IO
     dev = _dev()
     g = np.random.default_rng(2)
     frames = g.integers(0, 256, (2,) + src + (3,), dtype=np.uint8)
+    frames[1, :, : max(1, src[1] // 3)] = 255                     # saturated and black regions: no overshoot, exact corners
+    frames[1, : max(1, src[0] // 4)] = 0
     out = ops.preprocess_u8(torch.from_numpy(frames).to(dev), dst[0], dst[1]).cpu()
     for i in range(2):
         ref = IO.read_color_image(frames[i], resize=(dst[1], dst[0]))
         assert out[i].shape == ref.shape
-        assert float((out[i] - ref).abs().max()) < 1e-4, float((out[i] - ref).abs().max())   # fp32 coordinate round-off (fma contraction): 0.03 grey levels; 1/255 = 3.9e-3
-    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+        bad = int((out[i] != ref).sum())
+        assert torch.equal(out[i], ref), "%d of %d values differ, max %.3g" % (bad, ref.numel(), float((out[i] - ref).abs().max()))
 
 
 def test_upscale_agrees_with_pil_bilinear_to_one_grey_level():
@@ -86,7 +94,7 @@ def test_pair_feeder_batches_match_the_reference_preparation():
                 r = recs[seen + i]
                 for key, j in (("image0", 0), ("image1", 1)):
                     ref = IO.read_color_image(decoded[2 * (seen + i) + j], resize=(196, 182))
-                    assert float((data[key][i].cpu() - ref).abs().max()) < 1e-4
+                    assert torch.equal(data[key][i].cpu(), ref)          # byte-exact resize
                 Kref = IO.correct_intrinsic_scale(torch.from_numpy(r["K_color0"]), 196 / 320, 182 / 240)
                 assert torch.allclose(data["K_color0"][i].cpu(), Kref, atol=1e-5)
             assert data["scene_id"] == [r["scene_id"] for r in recs[seen:seen + n]]
