@@ -258,6 +258,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--heads-dtype", default="auto", choices=["auto", "same", "bf16", "fp16", "fp32"],
+                    help="AMD.HEADS_DTYPE of the headline model: operand type of the four head stacks (auto = fp16 beside a "
+                         "16-bit encoder; the reference runs them in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
@@ -465,10 +468,10 @@ def main(argv=None):
         ops.gemm_set_tile(500)
     ops.attn_set_mode(args.attn_mode)
 
-    def make_model(dtype, heads_fp32=False, arch="vit_large", matcher=None):
+    def make_model(dtype, heads=None, arch="vit_large", matcher=None):
         cfg = default_cfg()
         cfg["AMD"]["ENCODER_DTYPE"] = dtype
-        cfg["AMD"]["HEADS_DTYPE"] = "fp32" if heads_fp32 else "same"
+        cfg["AMD"]["HEADS_DTYPE"] = heads or args.heads_dtype
         cfg["AMD"]["SEED"] = rank
         cfg["AMD"]["LN_FOLD"] = not args.no_ln_fold
         cfg["AMD"]["GRAPH"] = {"auto": "auto", "on": True, "off": False}[args.graph]
@@ -576,7 +579,7 @@ def main(argv=None):
         leg("fp16", "fp16 operands everywhere: the reference's shipped low-precision mode for the encoder "
             "(MICKEY.DINOV2.FLOAT16), heads in fp16 too", "fp16", args.steps, args.warmup)
         leg("ref_split", "fp16 encoder + fp32 heads (fp32 MFMA): the reference's exact precision split "
-            "(mickey_extractor.py:49-56)", "fp16", max(3, args.steps // 4), 1, heads_fp32=True)
+            "(mickey_extractor.py:49-56)", "fp16", max(3, args.steps // 4), 1, heads="fp32")
         if "fp16" in out.get("legs", {}):
             out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
                           "note": "= legs.fp16 (kept for readers of the round-2 line)"}

@@ -35,6 +35,24 @@ def resolve_encoder_dtype(cfg):
     return _LP[v]
 
 
+def resolve_heads_dtype(cfg, encoder_dtype):
+    """AMD.HEADS_DTYPE: operand type of the four head stacks (reference mickey_extractor.py:53-56 always runs them in fp32).
+    'auto': fp16 beside a 16-bit encoder -- the heads' activations are BatchNorm outputs and the encoder's final-norm tokens
+    (which the reference's shipped fp16 mode itself holds in fp16, mickey_extractor.py:49-51), fp16's 11 bits run at the bf16
+    MFMA rate and take the heads' share of the bf16 mode's noise down 8x; fp32 beside the fp32 parity encoder.
+    'same' = the encoder's type, or bf16 | fp16 | fp32 (exact: fp32 MFMA)."""
+    v = str(cfg["AMD"].get("HEADS_DTYPE", "auto")).lower()
+    if v == "auto":
+        return torch.float32 if encoder_dtype == torch.float32 else torch.float16
+    if v == "same":
+        return encoder_dtype
+    if v not in _LP:
+        raise ValueError("AMD.HEADS_DTYPE must be auto | same | bf16 | fp16 | fp32, got %r" % v)
+    if encoder_dtype == torch.float32 and _LP[v] != torch.float32:
+        raise ValueError("AMD.HEADS_DTYPE: %s needs a 16-bit AMD.ENCODER_DTYPE (the fp32 parity mode runs everything in fp32)" % v)
+    return _LP[v]
+
+
 class _SolverView:
     """Attribute view of the PROCRUSTES config (reference probabilisticProcrustes.py:12-20)."""
 
@@ -82,7 +100,7 @@ class MickeyRelativePose(nn.Module):
         self.cfg = as_cfg(cfg)
         amd = self.cfg["AMD"]
         self.lp_dtype = resolve_encoder_dtype(self.cfg)
-        self.heads_fp32 = str(amd.get("HEADS_DTYPE", "same")).lower() in ("fp32", "float32")
+        self.heads_dtype = resolve_heads_dtype(self.cfg, self.lp_dtype)
         self.lean = bool(amd.get("LEAN", False))
         self.ln_fold = bool(amd.get("LN_FOLD", True))   # norm1 / norm2 folded into the GEMMs around them (16-bit modes)
         self.ln_centre = bool(amd.get("LN_CENTRE", True))   # ... with the residual stream kept row-centred
@@ -210,7 +228,7 @@ class MickeyRelativePose(nn.Module):
             if fm["TYPE"] == "DualSoftmax" and fm["DUAL_SOFTMAX"]["USE_DUSTBIN"] and DUSTBIN_KEY not in self._sd:
                 raise RuntimeError("FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN is set but the checkpoint has no %s (the "
                                    "reference's strict load fails on this too)" % DUSTBIN_KEY)
-            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_fp32=self.heads_fp32,
+            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_dtype=self.heads_dtype,
                                                 ln_fold=self.ln_fold, ln_centre=self.ln_centre)
         return self._dev_weights
 

@@ -104,12 +104,12 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_fp32=False, ln_fold=True, ln_centre=True):
-    """heads_fp32: keep the four head stacks' operands in fp32 (the reference always runs them in fp32,
-    mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True):
+    """heads_dtype: operand type of the four head stacks (None = lp_dtype; torch.float32 = as the reference, which always
+    runs them in fp32, mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
     W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold, ln_centre=ln_centre)
     dev = device
-    W.lp_heads = torch.float32 if heads_fp32 else lp_dtype
+    W.lp_heads = lp_dtype if heads_dtype is None else heads_dtype
 
     def lp(t):
         return t.to(device=dev, dtype=W.lp_heads).contiguous()
