@@ -11,12 +11,13 @@ does (the reference's own low-precision switch is `x.to(amp_dtype)` + a half-pre
 48-51) -- and stores rel-Frobenius(low precision, fp32) per output, for
 
     scope  "enc"       encoder in 16 bit, heads in fp32            (the reference's split; AMD.HEADS_DTYPE: fp32 / split)
-           "encheads"  encoder AND the four head stacks in 16 bit  (what AMD.HEADS_DTYPE: same computes)
+           "encheads"  encoder AND the four head stacks in 16 bit  (what AMD.HEADS_DTYPE: same computes; bf16 only)
     size   "182"  2 pairs of 182 x 196 (the golden case of tests/golden/full_forward.npz)
            "720"  1 pair of 720 x 540  (the Map-free size)
+           "vits720"  the same pair through a DINOv2 ViT-S/14 encoder (the size BASELINE.json's north_star names)
     dtype  "bf16", "fp16"
 
-as scalars named  <dtype>_<scope>_<size>_<key>.  Where /root/reference exists (the build container) the REFERENCE ITSELF is
+as scalars named  <dtype>_<scope>_<size>_<key> (plus ..._kps0_maxabs: the largest keypoint displacement in pixels).  Where /root/reference exists (the build container) the REFERENCE ITSELF is
 run as well, through its own low-precision mechanism (`dinov2.to(amp_dtype)`: the whole ViT incl. its residual stream in 16
 bit, heads fp32) with amp_dtype = float16 -- the mode it ships, FLOAT16: True -- and bfloat16:  ref_<dtype>_<size>_<key>
 (fp16 at 182 repeats tests/golden/noise_floor_fp16.npz).  The matcher and everything behind it stay fp32 (as in the reference and in
@@ -96,33 +97,47 @@ def reference_floors(cfg, sd, batch, size, floor):
         d["final_scores"] = d["scores"] * d["kp_scores"]
         for k in KEYS:
             floor["ref_%s_%s_%s" % (name, size, k)] = rel(d[k], d32[k])
+        floor["ref_%s_%s_kps0_maxabs" % (name, size)] = float((d["kps0"] - d32["kps0"]).abs().max())
         print("ref  %s     %s: " % (name, size) + "  ".join("%s %.2e" % (k, floor["ref_%s_%s_%s" % (name, size, k)])
                                                               for k in KEYS[::2] + KEYS[-2:-1]))
     ref_shim.uninstall()
 
 
-def main(out_dir=None, sizes=("182", "720")):
+def main(out_dir=None, sizes=("182", "720", "vits720")):
+    import copy
     torch.set_num_threads(os.cpu_count())
-    cfg = default_cfg()
-    sd = syn.mickey_state_dict(cfg, seed=0)
-    cases = {"182": dict(B=2, H=182, W=196, seed=1234), "720": dict(B=1, H=720, W=540, seed=1234)}
+    cfg_l = default_cfg()
+    sd_l = syn.mickey_state_dict(cfg_l, seed=0)
+    cfg_s = copy.deepcopy(cfg_l)
+    cfg_s["AMD"]["VIT"] = "vit_small"
+    cfg_s["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = 384
+    cases = {"182": dict(B=2, H=182, W=196, seed=1234), "720": dict(B=1, H=720, W=540, seed=1234),
+             "vits720": dict(B=1, H=720, W=540, seed=1234)}
     floor = {}
     with torch.no_grad():
         for size in sizes:
             batch = syn.synthetic_batch(**cases[size])
-            ref = correspondences(sd, cfg, batch)
+            if size == "vits720":
+                cfg, sd, nh = cfg_s, syn.mickey_state_dict(cfg_s, seed=0, arch="vit_small"), 6
+            else:
+                cfg, sd, nh = cfg_l, sd_l, 16
+            ref = correspondences(sd, cfg, batch, heads=nh)
             if size == "182":    # the fp32 leg IS the oracle the golden fixtures pin: same numbers as O.compute_correspondences
                 chk = O.compute_correspondences(sd, cfg, {k: v.clone() for k, v in batch.items()})
                 assert all(torch.equal(chk[k], ref[k]) for k in KEYS)
             for name, lp in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
                 for scope in ("enc", "encheads"):
-                    low = correspondences(sd, cfg, batch, lp, scope)
+                    if name == "fp16" and scope == "encheads":
+                        continue   # torch-CPU fp16 kernels ACCUMULATE in fp16: the heads' sums over n = 1938 pixels lose all
+                        #            precision (dsc 1.5e-1 at 720x540) -- an artefact of that backend, not a floor of fp16 operands
+                    low = correspondences(sd, cfg, batch, lp, scope, heads=nh)
                     for k in KEYS:
                         floor["%s_%s_%s_%s" % (name, scope, size, k)] = rel(low[k], ref[k])
+                    floor["%s_%s_%s_kps0_maxabs" % (name, scope, size)] = float((low["kps0"] - ref["kps0"]).abs().max())   # pixels
                     print("%s %-8s %s: " % (name, scope, size) +
                           "  ".join("%s %.2e" % (k, floor["%s_%s_%s_%s" % (name, scope, size, k)]) for k in KEYS[::2] + KEYS[-2:-1]))
             from oracle import ref_shim
-            if ref_shim.available():
+            if ref_shim.available() and size != "vits720":   # the reference only instantiates vit_large
                 reference_floors(cfg, sd, batch, size, floor)
     path = os.path.join(out_dir or GOLD, "noise_floor_lp.npz")
     np.savez(path, **{k: np.float64(v) for k, v in floor.items()})

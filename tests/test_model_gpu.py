@@ -3,26 +3,31 @@ reference's own outputs (tests/golden) and against the CPU oracle on the same se
 
 Tolerances: the HIP path computes the encoder and head contractions with 16-bit MFMA operands and fp32
 accumulation (the reference ships an fp16 encoder + fp32 heads); its distance to the fp32 oracle is a
-precision noise floor, not an algorithmic difference.  The floor of the REFERENCE's own fp16 mode on the
-golden case is stored in tests/golden/noise_floor_fp16.npz; bounds below are stated per quantity."""
+precision noise floor, not an algorithmic difference.  Every 16-bit bound below is an ORACLE-SIDE number from
+tests/golden/noise_floor_lp.npz (oracle/make_noise_floor.py) and the HIP error is asserted at <= 1.0 x it:
+
+  bf16   `bf16_encheads_<size>_<key>`: the fp32 oracle vs the same oracle with every contraction of the encoder and of the
+         four head stacks in bf16 (torch CPU autocast) -- the floor of an all-bf16 evaluation of this network;
+  fp16   `ref_fp16_<size>_<key>`: the REFERENCE ITSELF, fp32 vs its own shipped fp16 mode (MICKEY.DINOV2.FLOAT16: fp16 ViT,
+         fp32 heads, mickey_extractor.py:31-35,49-56) -- at 182x196 the same numbers as tests/golden/noise_floor_fp16.npz;
+  fp32   the exact parity mode (fp32-input MFMA): 1e-4, SURVEY.md 8(c) row 1.
+
+Nothing here is derived from the kernels' own output (round 3 asserted "1.5 x what the kernels measure")."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 KEYS = ("kps0", "kps1", "depth_kp0", "depth_kp1", "scr0", "scr1", "dsc0", "dsc1", "scores", "kp_scores", "final_scores")
-# rel-Frobenius bounds vs the fp32 reference.  bf16 (8 mantissa bits): 1.5x the LARGER of what round 3 measures on MI355X at
-# 182x196 against the reference golden / at 720x540 against the oracle (kps 4.8e-5 / 1.5e-5, depth 1.9e-3 / 2.0e-3, scr 7.7e-3 /
-# 7.2e-3, dsc 6.7e-3 / 6.9e-3, scores 5.8e-3 / 1.07e-2, kp_scores 1.08e-2 / 1.01e-2, final_scores 1.18e-2 / 1.11e-2), with no
-# further allowance at full size.  fp16 (11 bits): ~2x measured (kps 3e-6, depth 2.8e-4, scr 8.4e-4, dsc 7.9e-4, scores 1.0e-3,
-# final_scores 1.3e-3) -- every fp16 figure lies INSIDE the floor of the reference's OWN fp16 mode (fp16 encoder + fp32 heads:
-# kps 9.1e-6, depth 3.6e-4, scr 1.36e-3, dsc 1.15e-3, scores 1.08e-3, tests/golden/noise_floor_fp16.npz) although the heads run
-# in fp16 here too.  fp32 (the exact parity mode, fp32-input MFMA): 1e-4, SURVEY.md 8(c) row 1.
-TOL = {
-    torch.bfloat16: dict(kps=8e-5, depth=3e-3, scr=1.16e-2, dsc=1.03e-2, scores=1.6e-2, kp_scores=1.62e-2, final_scores=1.77e-2),
-    torch.float16: dict(kps=5e-5, depth=1.5e-3, scr=3e-3, dsc=2e-3, scores=2e-3, kp_scores=6e-3, final_scores=4e-3),
-    torch.float32: dict(kps=1e-4, depth=1e-4, scr=1e-4, dsc=1e-4, scores=1e-4, kp_scores=1e-4, final_scores=1e-4),
-}
+FLOOR_OF = {torch.bfloat16: "bf16_encheads", torch.float16: "ref_fp16"}
+
+
+def tol_for(golden, lp_dtype, size):
+    """{key: bound} for a forward whose encoder runs in lp_dtype, at size '182' | '720' | 'vits720'."""
+    if lp_dtype == torch.float32:
+        return {k: 1e-4 for k in KEYS}
+    fl = golden("noise_floor_lp")
+    return {k: float(fl["%s_%s_%s" % (FLOOR_OF[lp_dtype], size, k)]) for k in KEYS}
 
 
 def _dev():
@@ -70,25 +75,29 @@ def test_vit_tiny_encoder_golden(golden):
         assert e < tol, (dt, e)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
-def test_full_forward_golden(golden, cfg, dtype):
-    """ViT-L, 2 pairs of 182x196: every data-dict output against the reference's (fp32) outputs."""
+@pytest.mark.parametrize("dtype,heads", [("bf16", "auto"), ("bf16", "same"), ("fp16", "auto"), ("fp32", "auto")])
+def test_full_forward_golden(golden, cfg, dtype, heads):
+    """ViT-L, 2 pairs of 182x196: every data-dict output against the reference's (fp32) outputs, each within 1.0 x the
+    oracle-side noise floor of its operand type.  ("bf16", "same") = bf16 operands in the heads too: the literal all-bf16
+    evaluation the bf16 floor was measured for; "auto" runs the heads on fp16 operands.)"""
     dev = _dev()
     from mickey_amd import synthetic as syn
     g = golden("full_forward")
-    model, _ = _model(cfg, dtype)
+    model, _ = _model(cfg, dtype, HEADS_DTYPE=heads)
     batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
     data = {k: v.to(dev) for k, v in batch.items()}
     R, t = model(data, return_inliers=True)
-    tol = TOL[model.lp_dtype]
+    tol = tol_for(golden, model.lp_dtype, "182")
     errs = {k: rel(data[k], g[k]) for k in KEYS}
-    print(dtype, {k: "%.2e" % v for k, v in errs.items()})
+    print(dtype, heads, {k: "%.2e (%.2f of the floor)" % (v, v / tol[k]) for k, v in errs.items()})
     for k in KEYS:
-        base = k.rstrip("01").replace("depth_kp", "depth")
-        assert errs[k] < tol[base], (k, errs[k])
+        assert errs[k] <= tol[k], (k, errs[k], tol[k])
     kp_max = float((data["kps0"].cpu() - torch.from_numpy(g["kps0"])).abs().max())
     print("max keypoint deviation %.3f px" % kp_max)
-    assert kp_max < (0.2 if dtype == "bf16" else 0.1), kp_max   # pixels (bf16: 0.08-0.11 measured, the largest of 364 keypoints)
+    if model.lp_dtype != torch.float32:   # pixels, the largest of 364 keypoints: not beyond what the oracle-side 16-bit evaluation moves one
+        kp_floor = float(golden("noise_floor_lp")["%s_182_kps0_maxabs" % FLOOR_OF[model.lp_dtype]])
+        assert kp_max <= kp_floor, (kp_max, kp_floor)
+    assert kp_max < 0.2, kp_max
     # contract: shapes / keys the reference's callers read
     assert R.shape == (2, 3, 3) and t.shape == (2, 1, 3) and data["inliers"].shape == (2, 1)
     assert data["kps0_shape"] == [13, 14] and data["depth0_map"].shape == (2, 1, 13, 14) and data["down_factor"] == 14
@@ -126,15 +135,16 @@ def test_heads_fp32_option_matches_reference_split(golden, cfg):
     model.compute_correspondences(data)
     errs = {k: rel(data[k], g[k]) for k in KEYS}
     print("fp16 encoder + fp32 heads", {k: "%.2e" % v for k, v in errs.items()})
-    tol = TOL[torch.float16]
+    tol = tol_for(golden, torch.float16, "182")
     for k in KEYS:
-        assert errs[k] < tol[k.rstrip("01").replace("depth_kp", "depth")], (k, errs[k])
+        assert errs[k] <= tol[k], (k, errs[k], tol[k])
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_full_size_pair_vs_oracle(cfg, dtype):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_full_size_pair_vs_oracle(golden, cfg, dtype):
     """One 720x540 pair (51x38 grid, n = 1938) against the CPU oracle run here on the same seeded
-    weights and inputs (extractor + matcher; ~20 s of CPU).  fp32 = the exact parity mode: <= 1e-4 everywhere."""
+    weights and inputs (extractor + matcher; ~20 s of CPU).  fp32 = the exact parity mode: <= 1e-4 everywhere; bf16 / fp16:
+    <= 1.0 x the oracle-side floor of that operand type at this size."""
     dev = _dev()
     from mickey_amd import synthetic as syn
     from oracle import mickey_oracle as O
@@ -143,12 +153,11 @@ def test_full_size_pair_vs_oracle(cfg, dtype):
     data = {k: v.to(dev) for k, v in batch.items()}
     model.compute_correspondences(data)
     odata = _oracle_720(cfg, sd, batch)
-    tol = TOL[model.lp_dtype]
+    tol = tol_for(golden, model.lp_dtype, "720")
     errs = {k: rel(data[k], odata[k]) for k in KEYS}
-    print("720x540", dtype, {k: "%.2e" % v for k, v in errs.items()})
+    print("720x540", dtype, {k: "%.2e (%.2f of the floor)" % (v, v / tol[k]) for k, v in errs.items()})
     for k in KEYS:
-        base = k.rstrip("01").replace("depth_kp", "depth")
-        assert errs[k] < tol[base], (k, errs[k])
+        assert errs[k] <= tol[k], (k, errs[k], tol[k])
     assert data["scores"].shape == (1, 1938, 1938)
     # row arg-max of the score matrix: identical wherever the oracle's top-2 gap exceeds the noise floor
     top2 = odata["scores"].topk(2, dim=2).values
@@ -167,7 +176,7 @@ def test_full_size_pair_vs_oracle(cfg, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_full_forward_vs_oracle_vit_small(cfg, dtype):
+def test_full_forward_vs_oracle_vit_small(golden, cfg, dtype):
     """The encoder size BASELINE.json's north_star names: DINOv2 ViT-S/14 (D = 384, 12 blocks, 6 heads; reference
     DINO_modules/dinov2.py:306-316) in front of the same heads / matcher, one 720x540 pair against the CPU oracle (heads=6).
     D = 384 takes the generic folded-LayerNorm path (6 statistics slots per row) and K = 384 GEMMs (6 K stages)."""
@@ -191,21 +200,17 @@ def test_full_forward_vs_oracle_vit_small(cfg, dtype):
     odata = {k: v.clone() for k, v in batch.items()}
     with torch.no_grad():
         odata.update(O.compute_correspondences(sd, c, odata, heads=6))
-    tol = TOL[model.lp_dtype]
+    tol = tol_for(golden, model.lp_dtype, "vits720")   # bf16: the oracle-side floor of THIS model (ViT-S encoder + heads in bf16)
     errs = {k: rel(data[k], odata[k]) for k in KEYS}
-    print("vit_small 720x540", dtype, {k: "%.2e" % v for k, v in errs.items()})
-    # keypoint positions: the sigmoid offsets of this (random-weight) ViT-S model are less damped than ViT-L's: 2.5e-4 rel
-    # (0.11 px RMS) measured in bf16 on MI355X against 3e-5 for ViT-L; asserted at 2x
-    tol = dict(tol, kps=max(tol["kps"], 5e-4 / 1.5)) if dtype != "fp32" else tol
+    print("vit_small 720x540", dtype, {k: "%.2e (%.2f of the floor)" % (v, v / tol[k]) for k, v in errs.items()})
     for k in KEYS:
-        base = k.rstrip("01").replace("depth_kp", "depth")
-        assert errs[k] < (1.0 if dtype == "fp32" else 1.5) * tol[base], (k, errs[k])
+        assert errs[k] <= tol[k], (k, errs[k], tol[k])
     assert data["scores"].shape == (1, 1938, 1938) and torch.isfinite(R).all() and torch.isfinite(t).all()
     det = torch.linalg.det(R.double().cpu())
     assert ((det - 1).abs() < 1e-4).all() or float(R.abs().sum()) == 0.0
 
 
-def test_row_centring_is_invisible(cfg):
+def test_row_centring_is_invisible(golden, cfg):
     """AMD.LN_CENTRE on / off: the encoder's residual stream with and without the per-row offset gives the same features to
     the operand type's noise floor (LayerNorm is the only reader of the stream), and the fp16 forward with centring stays
     inside the bounds of the reference golden."""
@@ -218,8 +223,9 @@ def test_row_centring_is_invisible(cfg):
         data = {k: v.to(dev) for k, v in batch.items()}
         model.compute_correspondences(data)
         outs[centre] = data
+    tol = tol_for(golden, torch.float16, "182")
     for k in ("dsc0", "scr0", "depth_kp0", "final_scores"):
-        assert rel(outs[True][k], outs[False][k]) < 2 * TOL[torch.float16][k.rstrip("01").replace("depth_kp", "depth")], k
+        assert rel(outs[True][k], outs[False][k]) < 2 * tol[k], k     # each within the floor of the truth: apart by <= 2 floors
         assert not torch.equal(outs[True][k], outs[False][k])   # the switch does something
 
 
