@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
       bool rebase = first;
       if (!first) {
         rs = exp_sum();
-        rebase = __any(!(rs <= ATT_REBASE_SUM));   // also true for inf / nan
+        rebase = __any(!(rs <= ATT_REBASE_SUM));   // also true for +inf (an overflowed sum); the file is built with
+                                                   // -fno-honor-nans, so nothing is claimed for NaN: finite q, k cannot make one
       }
       if (rebase) {   // the first tile, and tiles that outgrew m: re-base m to this tile's maximum
         float t8[8];

@@ -160,7 +160,8 @@ class PairFeeder:
                 slot, futs = pending.pop(bi)
                 for f in futs:
                     f.result()
-                ring.upload(slot)
+                if len(batch):          # an empty slice has nothing to copy (the slot's pinned memory holds stale frames)
+                    ring.upload(slot)
                 nxt = bi + ahead
                 if nxt < len(batches):
                     pending[nxt] = stage(nxt)   # decode the batch after next while this one is copied / computed

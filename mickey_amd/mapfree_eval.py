@@ -148,8 +148,7 @@ def predict_to_zip(model, records, batch_size, resize, output_zip, sharded=False
                 inl = data["inliers"]
         sio.append_batch(results, [r["scene_id"] for r in gb], [r["pair_names"][1] for r in gb], R.detach().cpu().numpy(),
                          t.detach().cpu().numpy(), inl.detach().cpu().numpy())
-    rank = int(os.environ.get("RANK", "0"))
-    if rank == 0:
+    if rank == 0:   # the rank resolved above (argument, else the process group's; 0 when not sharded)
         sio.save_submission(results, output_zip)
     return results
 

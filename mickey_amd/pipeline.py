@@ -89,7 +89,9 @@ def encoder_forward(W, ws, img):
             ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out=hid)
             ops.gemm_ls_residual(hid, blk.fc2_w, blk.fc2_b, blk.g2, x)
     # the heads' operand type, as a BORDERED feature map (mickey_hip.h: what a 3x3 conv reads; border rows stay zero)
-    feat = ws.get("feat", (ops.bordered_rows(nimg, gh, gw), D), getattr(W, "lp_heads", lp), dev, zero=True)
+    # (bordered buffers are zeroed ONCE and only their pixel rows are ever written: the key carries the geometry, because two
+    # geometries can share a row count while their border rows sit elsewhere)
+    feat = ws.get("feat_%d_%d_%d" % (nimg, gh, gw), (ops.bordered_rows(nimg, gh, gw), D), getattr(W, "lp_heads", lp), dev, zero=True)
     ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
                   bordered=(nimg, gh, gw))
     return feat, gh, gw
@@ -105,14 +107,15 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     G = 4
     mk = cfg["MICKEY"]
     R = ops.bordered_rows(nimg, gh, gw)
+    geo = "_%d_%d_%d" % (nimg, gh, gw)   # bordered buffers: the workspace key carries the geometry (see encoder_forward)
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
     for bi, rb in enumerate(W.rb):
         co = rb.cout
         last = bi == len(W.rb) - 1   # its output feeds the attention layers (row-wise kernels): dense rows
-        h1 = ws.get("rb%d_h" % bi, (G, R, co), lp, dev, zero=True)
+        h1 = ws.get("rb%d_h" % bi + geo, (G, R, co), lp, dev, zero=True)
         ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
                     stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
-        xo = ws.get("rb%d_x" % bi, (G, M if last else R, co), lp, dev, zero=not last)
+        xo = ws.get("rb%d_x" % bi + geo, (G, M if last else R, co), lp, dev, zero=not last)
         ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=x_in, C2=c_in,
                     stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
                     stride_out=(M if last else R) * co, out_bordered=not last)
@@ -134,7 +137,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     msg = ws.get("att_msg", (G, M, C), lp, dev)
     mrg = ws.get("att_mrg", (G, M, C), torch.float32, dev)
     hid = ws.get("att_hid", (G, M, 2 * C), lp, dev)
-    x4 = ws.get("att_out", (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
+    x4 = ws.get("att_out" + geo, (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
     nl = len(W.att)
     for li, lay in enumerate(W.att):
         ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
@@ -152,7 +155,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout
-    h4 = ws.get("rb4_h", (3, R, ck), lp, dev, zero=True)
+    h4 = ws.get("rb4_h" + geo, (3, R, ck), lp, dev, zero=True)
     ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
                 stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
     f4 = ws.get("rb4_f", (3, M, ck), torch.float32, dev)
@@ -161,7 +164,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
                 stride_in2=R * C, stride_resid=R * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck,
                 stride_out=M * ck)
     cd = dw.cout
-    hd = ws.get("rb4_hd", (R, cd), lp, dev, zero=True)
+    hd = ws.get("rb4_hd" + geo, (R, cd), lp, dev, zero=True)
     ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
     ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246

@@ -178,8 +178,11 @@ class MetricPoseLoss(torch.nn.Module):
             return bail()
         loss_value_k, loss_rot_k, loss_trans_k, score_k = (v.reshape(Ro, it_r) for v in (loss_value_k, loss_rot_k, loss_trans_k, score_k))
         sm = torch.softmax(score_k / self.score_temperature, -1)
-        loss_rot = (loss_rot_k * sm).sum(-1).unsqueeze(-1)
-        loss_trans = (loss_trans_k * sm).sum(-1).unsqueeze(-1)
+        # rotation / translation errors are LOGGING outputs here (the reference logs them, model.py:151-171, and optimises
+        # avg_loss only): the native tail returns them without a gradient, so they are aggregated with a DETACHED softmax --
+        # backpropagating avg_loss_rot / avg_loss_trans raises instead of silently yielding the partial gradient through `sm`
+        loss_rot = (loss_rot_k * sm.detach()).sum(-1).unsqueeze(-1)
+        loss_trans = (loss_trans_k * sm.detach()).sum(-1).unsqueeze(-1)
         if self.add_null_hypothesis:
             loss_value_k = torch.cat([loss_value_k, torch.full((Ro, 1), float(self.max_loss_null), device=dev)], -1)
             score_k = torch.cat([score_k, torch.full((Ro, 1), float(self.th_outliers * S), device=dev)], -1)

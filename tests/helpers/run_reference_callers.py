@@ -3,7 +3,7 @@ submission.predict / save_submission (submission.py:32-68) -- against the drop-i
 
 Executed as a subprocess by tests/test_reference_callers.py with
     PYTHONPATH = <this repo>:<reference checkout>      (the overlay of INTEGRATION.md section 1)
-so `lib.models.builder` / `lib.models.MicKey.compute_pose` / `lib.utils.data` resolve HERE and every other module the
+so `lib.models.builder` / `lib.models.MicKey.compute_pose` resolve HERE and every other module the
 callers import (config.default, lib.datasets.utils, lib.utils.visualization, lib.models.MicKey.modules...training_utils)
 stays the reference's.  Third-party modules absent from this container are stood in for by ref_env_shims.
 

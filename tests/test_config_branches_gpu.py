@@ -1,0 +1,80 @@
+"""-m gpu: the NON-DEFAULT configuration branches the kernels implement, each as a whole forward (encoder + heads + matcher)
+against the CPU oracle in the exact-fp32 mode at <= 1e-4:
+
+  MICKEY.KP_HEADS.USE_SOFTMAX: False       sigmoid detector + border mask        reference mickey_extractor.py:135-140
+  MICKEY.KP_HEADS.USE_DEPTHSIGMOID: True   depth = MAX_DEPTH * sigmoid(.)        mickey_extractor.py:213-216
+  MICKEY.DSC_HEAD.NORM_DSC: False          un-normalised descriptors             mickey_extractor.py:246-249
+  MICKEY.KP_HEADS / DSC_HEAD.POS_ENCODING  no sine position encoding (one / both head groups: the two differ -> the
+                                           split posenc launch of pipeline.heads_forward)    att_layers/transformer.py:92-93
+  FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN: False   plain dual softmax            utils/feature_matcher.py:66-83
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("kps0", "kps1", "depth_kp0", "depth_kp1", "scr0", "scr1", "dsc0", "dsc1", "scores", "kp_scores", "final_scores")
+BRANCHES = {
+    "sigmoid_detector": [("MICKEY", "KP_HEADS", "USE_SOFTMAX", False)],
+    "depth_sigmoid": [("MICKEY", "KP_HEADS", "USE_DEPTHSIGMOID", True)],
+    "raw_descriptors": [("MICKEY", "DSC_HEAD", "NORM_DSC", False)],
+    "no_posenc_kp": [("MICKEY", "KP_HEADS", "POS_ENCODING", False)],
+    "no_posenc_dsc": [("MICKEY", "DSC_HEAD", "POS_ENCODING", False)],
+    "no_posenc": [("MICKEY", "KP_HEADS", "POS_ENCODING", False), ("MICKEY", "DSC_HEAD", "POS_ENCODING", False)],
+    "no_dustbin": [("FEATURE_MATCHER", "DUAL_SOFTMAX", "USE_DUSTBIN", False)],
+    "all_flipped": [("MICKEY", "KP_HEADS", "USE_SOFTMAX", False), ("MICKEY", "KP_HEADS", "USE_DEPTHSIGMOID", True),
+                    ("MICKEY", "KP_HEADS", "POS_ENCODING", False), ("FEATURE_MATCHER", "DUAL_SOFTMAX", "USE_DUSTBIN", False)],
+}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("branch", sorted(BRANCHES))
+def test_branch_vs_oracle_fp32(cfg, branch):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mickey_amd import synthetic as syn
+    from mickey_amd.model import MickeyRelativePose
+    from oracle import mickey_oracle as O
+    dev = torch.device("cuda:0")
+    c = copy.deepcopy(cfg)
+    c["AMD"]["ENCODER_DTYPE"] = "fp32"
+    for a, b, k, v in BRANCHES[branch]:
+        assert c[a][b][k] != v, "not a non-default value"
+        c[a][b][k] = v
+    sd = syn.mickey_state_dict(c, seed=0)
+    model = MickeyRelativePose(c)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
+    data = {k: v.to(dev) for k, v in batch.items()}
+    R, t = model(data)
+    odata = {k: v.clone() for k, v in batch.items()}
+    with torch.no_grad():
+        odata.update(O.compute_correspondences(sd, c, odata))
+    errs = {k: rel(data[k], odata[k]) for k in KEYS}
+    print(branch, {k: "%.2e" % v for k, v in errs.items()})
+    tol = {k: 1e-4 for k in KEYS}
+    if branch == "raw_descriptors":
+        # the logits of the dual softmax are dsc0 . dsc1 / 0.1 of UN-normalised descriptors: |logit| reaches L = max |S| / T
+        # and an fp32 round-off of the 128-term dot product, ~1e-6 relative, becomes ~1e-6 * L ABSOLUTE in the exponent --
+        # the oracle's own CPU BLAS has the same spread; the bound scales with L (measured on the oracle's descriptors)
+        L = float(torch.matmul(odata["dsc0"].transpose(1, 2), odata["dsc1"]).abs().max()) / 0.1
+        for k in ("scores", "final_scores"):
+            tol[k] = max(1e-4, 4e-6 * L)
+        print("raw descriptors: max |logit| %.0f -> scores bound %.1e" % (L, tol["scores"]))
+    for k in KEYS:
+        assert errs[k] <= tol[k], (branch, k, errs[k], tol[k])
+    # the branch really was taken: the flipped switch changes the outputs it governs
+    base = {k: v.clone() for k, v in batch.items()}
+    with torch.no_grad():
+        base.update(O.compute_correspondences(sd, cfg, base))
+    moved = {"sigmoid_detector": "scr0", "depth_sigmoid": "depth_kp0", "raw_descriptors": "dsc0", "no_posenc_kp": "scr0",
+             "no_posenc_dsc": "dsc0", "no_posenc": "dsc0", "no_dustbin": "scores", "all_flipped": "scores"}[branch]
+    assert rel(odata[moved], base[moved]) > 1e-3
+    assert torch.isfinite(R).all() and torch.isfinite(t).all()
