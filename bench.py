@@ -220,18 +220,57 @@ def cpu_baseline(cfg, sd):
             data.update(out)
             O.estimate_pose(data, cfg)
             t4 = time.perf_counter()
+            cpu_baseline.last_outputs = {k: v for k, v in out.items()}   # the oracle's features of this pair (precision report)
         t.update(encoder=t1 - t0, heads=t2 - t1, matcher=t3 - t2, solver=t4 - t3, total=t4 - t0)
         return t
 
     one(False)   # warm-up (thread pools, allocator, first-touch of the weights)
     runs = [one(True) for _ in range(3)]
     med = {k: sorted(r[k] for r in runs)[1] for k in runs[0]}
-    return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
+            "kind_note": "the oracle restatement, not the reference module itself: /root/reference does not exist on the GPU box; "
+                         "threads capped at 32 because torch-CPU gets slower beyond that on these ops",
             "pinned_by": "tests/test_oracle_golden.py (the oracle vs the reference's own outputs, tests/golden/*.npz, regenerated "
                          "from /root/reference by oracle/make_golden.py in test_committed_fixtures_reproduce_from_the_reference)",
             "protocol": "1 warm-up + median of 3", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
             "sample": "1 pair 540x720, full forward (ViT-L fp32 + heads + dual-softmax + 20x100 RANSAC), torch-CPU "
                       "oracle, median %.2f s per pair" % med["total"]}
+
+
+def precision_report(make_model, syn, dev, args, oracle_out):
+    """rel-Frobenius error of every feature output vs the CPU oracle (fp32) on the one 540x720 pair the cpu_baseline leg
+    computed in this run, for the headline configuration and the fp16 leg, next to the committed oracle-side noise floors
+    (tests/golden/noise_floor_lp.npz, oracle/make_noise_floor.py)."""
+    import numpy as np
+    import torch
+    keys = ("kps0", "depth_kp0", "scr0", "dsc0", "scores", "final_scores")
+    floors = None
+    fp = os.path.join(ROOT, "tests", "golden", "noise_floor_lp.npz")
+    if os.path.exists(fp):
+        floors = np.load(fp)
+    rep = {}
+    for name, dtype, floor_key in (("headline", args.dtype, "bf16_encheads_720_" if args.dtype == "bf16" else "ref_fp16_720_"),
+                                   ("fp16", "fp16", "ref_fp16_720_")):
+        if name == "fp16" and args.dtype == "fp16":
+            rep["fp16"] = rep["headline"]
+            continue
+        m = make_model(dtype)[0]
+        d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=1, H=H, W=W, seed=1234).items()}
+        m.compute_correspondences(d)
+        torch.cuda.synchronize()
+        err = {}
+        for k in keys:
+            a, b = d[k].double().cpu(), oracle_out[k].double()
+            err[k] = float((a - b).norm() / (b.norm() + 1e-30))
+        ent = {"dtype": dtype, "heads_operands": str(m.heads_dtype).replace("torch.", ""), "error_vs_oracle": err}
+        if floors is not None:
+            ent["floor"] = {k: float(floors[floor_key + k]) for k in keys}
+            ent["floor_source"] = "tests/golden/noise_floor_lp.npz:" + floor_key + "*"
+            ent["inside_floor"] = all(err[k] <= ent["floor"][k] for k in keys)
+        rep[name] = ent
+        del m, d
+        torch.cuda.empty_cache()
+    return rep
 
 
 def free_port():
@@ -261,6 +300,7 @@ def parse_args(argv=None):
     ap.add_argument("--heads-dtype", default="auto", choices=["auto", "same", "bf16", "fp16", "fp32"],
                     help="AMD.HEADS_DTYPE of the headline model: operand type of the four head stacks (auto = fp16 beside a "
                          "16-bit encoder; the reference runs them in fp32)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
@@ -379,9 +419,34 @@ def measure(model, data0, args, use_dist, world, gatherer, prof=None):
         prof.on = False
     if use_dist:
         tt = torch.tensor([dt], device=data0["image0"].device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)           # every rank's own wall time: the line reports min / max, `value` uses the MAX
+        measure.per_rank_s = [float(t.item()) for t in every]
+        dt = max(measure.per_rank_s)
+    else:
+        measure.per_rank_s = [dt]
     return dt, last, poses
+
+
+def per_rank_ms(steps):
+    """min / max / all of the ranks' own ms per step of the last measure() (the first thing to look at when a scaling run
+    disappoints: one slow rank, or all of them)."""
+    ms = [t / steps * 1e3 for t in getattr(measure, "per_rank_s", [])]
+    return {"min": min(ms), "max": max(ms), "all": [round(m, 3) for m in ms]} if ms else None
+
+
+def place_rank(args, rank, world, use_dist):
+    """N > 1: pin every rank to its GPU's NUMA cores (or an even split of the allowed cores), mickey_amd.distributed.pin_rank;
+    returns the list of all ranks' placements on rank 0 (None elsewhere / at N = 1 / with --no-pin)."""
+    import torch.distributed as dist
+    from mickey_amd import distributed as D
+    if not use_dist or args.no_pin:
+        return None
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    mine = D.pin_rank(int(os.environ.get("LOCAL_RANK", rank)), local_world)
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    return every if rank == 0 else None
 
 
 def main_stub(args, rank, world, use_dist):
@@ -393,6 +458,7 @@ def main_stub(args, rank, world, use_dist):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo", rank=rank, world_size=world)
         world = dist.get_world_size()
+    affinity = place_rank(args, rank, world, use_dist)
     B = args.batch
     g = torch.Generator().manual_seed(1234 + 2 * rank)
     data0 = {"image0": torch.rand((B, 3, 8, 8), generator=g), "image1": torch.rand((B, 3, 8, 8), generator=g)}
@@ -406,7 +472,8 @@ def main_stub(args, rank, world, use_dist):
         print(json.dumps({"metric": "image pairs/sec (540x720)", "stub": True, "value": world * B * args.steps / dt,
                           "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
-                          "config": {"pairs_per_gpu": B, "global_batch": world * B}}), flush=True)
+                          "per_rank_ms_per_step": per_rank_ms(args.steps),
+                          "config": {"pairs_per_gpu": B, "global_batch": world * B, "affinity": affinity}}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -457,6 +524,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()   # what RCCL actually saw
+    affinity = place_rank(args, rank, world, use_dist)
 
     from mickey_amd import distributed as D
     from mickey_amd import ops, synthetic as syn
@@ -531,7 +599,9 @@ def main(argv=None):
                        "pairs_per_gpu": B, "global_batch": world * B, "image_hw": [H, W], "keypoints": 1938,
                        "hypotheses": 2000, "parallelism": "pairs sharded over %d GPU(s), 1 all-gather of poses "
                                                           "(side stream)" % world,
-                       "hip_graph": graphed},
+                       "hip_graph": graphed, "heads_operands": str(model.heads_dtype).replace("torch.", ""),
+                       "affinity": affinity},
+            "per_rank_ms_per_step": per_rank_ms(args.steps),
             "roofline": roof,
             "finite_output": ok,
         }
@@ -607,6 +677,21 @@ def main(argv=None):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
+            # precision of the timed configurations against the oracle outputs of THIS run (the pair the CPU leg just computed)
+            try:
+                out["precision"] = precision_report(make_model, syn, dev, args, cpu_baseline.last_outputs)
+                fl = out["precision"].get("fp16")
+                if fl and "fp16" in out.get("legs", {}):
+                    leg16 = out["legs"]["fp16"]
+                    out["precision_matched"] = {
+                        "what": "the precision-matched number: fp16 operands (the reference ships an fp16 encoder, "
+                                "MICKEY.DINOV2.FLOAT16: True) -- every output lies inside the reference's OWN fp16-vs-fp32 noise "
+                                "floor; = legs.fp16",
+                        "dtype": "fp16", "value": leg16["value"], "unit": "pairs/s", "ms_per_step": leg16["ms_per_step"],
+                        "stages": leg16.get("stages"), "error_vs_oracle": fl["error_vs_oracle"],
+                        "reference_fp16_floor": fl.get("floor"), "inside_floor": fl.get("inside_floor")}
+            except Exception as e:   # a reporting leg must not lose the measured line
+                out["precision"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

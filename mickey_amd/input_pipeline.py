@@ -108,7 +108,10 @@ class PairFeeder:
             records = [r for b in self._batches for r in b]
         self.records, self.B, self.resize = list(records), int(batch_size), (int(resize[0]), int(resize[1]))
         self.device = torch.device(device)
-        self.workers = workers or min(32, max(2, (os.cpu_count() or 4) // 2))
+        # decode pool: half of the cores THIS process may run on (a rank pinned by distributed.pin_rank sizes its pool to its
+        # own share; os.cpu_count() would give every one of 8 ranks a pool for the whole machine)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+        self.workers = workers or min(32, max(2, ncpu // 2))
         self.slots = slots
         self._ring = None
 

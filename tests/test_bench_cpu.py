@@ -52,6 +52,24 @@ def test_gpus_2_spawns_two_ranks_under_gloo():
     assert out["n_gpus"] == 2 and out["stub"] is True and out["config"]["global_batch"] == 6 and out["steps"] == 2
 
 
+def test_gpus_8_stub_reports_every_rank():
+    """The world size the driver's scaling run ends at: 8 ranks launch, one line, per-rank step times (min / max / all)
+    and each rank's CPU placement (an even split of the allowed cores here: no NUMA information without a GPU)."""
+    r = _run(["--gpus", "8"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 24
+    pr = out["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 8 and pr["min"] <= pr["max"] and abs(pr["max"] - out["ms_per_step"]) < 1e-6
+    aff = out["config"]["affinity"]
+    assert len(aff) == 8 and all("n_cpus" in a and a["n_cpus"] >= 1 for a in aff)
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert sum(a["n_cpus"] for a in aff) == ncpu      # a partition of the allowed cores
+
+
 def test_gpus_1_is_single_process():
     r = _run(["--gpus", "1"])
     assert r.returncode == 0, r.stderr[-2000:]

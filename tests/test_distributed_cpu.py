@@ -44,14 +44,14 @@ def _worker(rank, world, port, B, q):
     dist.destroy_process_group()
 
 
-def _run(B):
+def _run(B, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -76,6 +76,33 @@ def test_fewer_pairs_than_ranks():
     """B = 1 on 2 ranks: the rank with the empty shard skips the model call but still joins the collective (a
     hang here is what submission_io.predict(sharded=True) would have hit on the last batch of an evaluation)."""
     _run(1)
+
+
+def test_world_8_ragged_and_sparse_batches():
+    """The node the driver scales to: 8 ranks.  A global batch of 12 gives shards of 2,2,2,2,1,1,1,1 (the padded
+    all-gather path), 16 the single-collective path, 5 leaves three ranks with an empty shard."""
+    _run(12, world=8)
+    _run(16, world=8)
+    _run(5, world=8)
+
+
+def test_affinity_plan_rules():
+    from mickey_amd.distributed import affinity_plan, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    # no NUMA information: an even contiguous split of what the process may use
+    plans = [affinity_plan(r, 8, range(64)) for r in range(8)]
+    assert plans[0] == list(range(0, 8)) and plans[7] == list(range(56, 64))
+    assert sorted(c for p in plans for c in p) == list(range(64))
+    # two sockets, GPUs 0-3 on node 0 (cpus 0-47, 96-143), 4-7 on node 1: each rank a quarter of ITS node, no overlap
+    n0, n1 = parse_cpulist("0-47,96-143"), parse_cpulist("48-95,144-191")
+    plans = [affinity_plan(r, 8, range(192), n0 if r < 4 else n1, (r % 4, 4)) for r in range(8)]
+    assert all(len(p) == 24 for p in plans) and sorted(c for p in plans for c in p) == list(range(192))
+    assert set(plans[0]) <= set(n0) and set(plans[5]) <= set(n1)
+    # a cgroup that allows only part of the node: the plan stays inside it; more ranks than cores: nobody gets an empty set
+    assert affinity_plan(1, 2, [4, 5, 6, 7], n0, (1, 2)) == [6, 7]
+    assert all(affinity_plan(r, 8, [0, 1, 2]) for r in range(8))
+    # NUMA cores that the process may not use at all -> fall back to the even split
+    assert affinity_plan(0, 2, [200, 201], n0, (0, 2)) == [200]
 
 
 def test_pose_gatherer_cpu_path_is_synchronous():
@@ -150,3 +177,18 @@ def test_sharded_evaluation_feeds_only_the_local_slice(tmp_path):
     assert seen0 == [0, 0] and seen1 == [2, 2]
     assert lines0 == lines1 and len(lines0) == 7
     assert wrote0 and not wrote1
+
+
+def test_eight_ranks_decoding_at_once_do_not_collapse():
+    """Row N1 at the node scale (tools/bench_decode_pool.py): 8 processes, each pinned to its share of the allowed cores and
+    running PairFeeder's decode pool, against one machine's decode budget -- no rank starves and together they are not
+    slower than one process with the same number of threads (which the GIL and core migration hold back)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_decode_pool as BD
+    many = BD.run(8, 1.0, 270, 360)
+    rates = [r[1] for r in many]
+    assert len(rates) == 8 and min(rates) > 0.25 * max(rates), rates
+    one = BD.run(1, 1.0, 270, 360, pin=False, threads=sum(r[3] for r in many))
+    assert sum(rates) > 0.5 * one[0][1], (rates, one)
