@@ -223,6 +223,19 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
                     int use_dustbin, float dustbin, float* scores, float* kp_scores, float* final_scores, float* work, int B,
                     int C, int n0, int n1, mk_stream_t stream);
 
+/* dualSoftmax.forward with the descriptor correlation on the 16-bit matrix cores (BASELINE.json configs[4]: "fp16 MFMA
+ * descriptor correlation"; reference feature_matcher.py:65 is an fp32 matmul): every descriptor entry is split into fp16 hi + lo
+ * parts (x 2^10 = hi + lo, 22 mantissa bits) and x0.x1 evaluated as lo.hi + hi.lo + hi.hi on v_mfma_f32_32x32x16_f16 with fp32
+ * accumulation -- fp32-grade values (<= 1e-5 rel vs the fp32 reference, same row / column arg-max), a sixth of the matrix
+ * time of the exact fp32 MFMA; the correlation is evaluated twice (statistics, then outputs) instead of being stored.
+ * PRECONDITIONS (else use mk_dual_softmax): C == 128; |dsc| <= 1 everywhere (L2-normalised descriptors,
+ * MICKEY.DSC_HEAD.NORM_DSC: True, extractor_utils.py:6-10); inv_temperature * log2(e) <= 100 (the row / column sums are
+ * taken without a running maximum).  Arguments as mk_dual_softmax; work: mk_dual_softmax_split_work_floats fp32 elements. */
+long long mk_dual_softmax_split_work_floats(int B, int n0, int n1);
+int mk_dual_softmax_split(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
+                          int use_dustbin, float dustbin, float* scores, float* kp_scores, float* final_scores, float* work,
+                          int B, int C, int n0, int n1, mk_stream_t stream);
+
 /* sinkhorn.forward (feature_matcher.py:93-137): 10 log-domain iterations on u, v only.
  *   scr0/scr1/kp_scores/final_scores as in mk_dual_softmax (optional).
  *   work: mk_sinkhorn_work_floats(B, n0, n1) fp32 elements (holds the (n0+1)x(n1+1) coupling matrix). */

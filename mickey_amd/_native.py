@@ -45,6 +45,8 @@ SIGNATURES = {
     "mk_head_tails": ("i", "pppppppppppiiiiiiiififp"),
     "mk_dual_softmax_work_floats": ("l", "iiii"),
     "mk_dual_softmax": ("i", "ppppfifppppiiiip"),
+    "mk_dual_softmax_split_work_floats": ("l", "iii"),
+    "mk_dual_softmax_split": ("i", "ppppfifppppiiiip"),
     "mk_sinkhorn_work_floats": ("l", "iii"),
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),

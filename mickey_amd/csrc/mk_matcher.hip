@@ -215,14 +215,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // side 0: rows (NCHUNK column-chunk partials each), side 1: columns (nrb row-block partials each)
 __global__ __launch_bounds__(256) void lse_final_kernel(const float* __restrict__ partr, const float* __restrict__ partc,
                                                         float* __restrict__ lse2, int use_dustbin, float beta2, int n0, int n1,
-                                                        int nmax, int nrb) {
+                                                        int nmax, int nrb, int nchunk) {
   const int idx = blockIdx.x * 256 + threadIdx.x, side = blockIdx.y, b = blockIdx.z;
   if (idx >= (side ? n1 : n0)) return;
   float m = -1e30f, s = 0.f;
   if (side == 0) {
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-      const float* q = partr + (((long long)b * NCHUNK + c) * n0 + idx) * 2;
+    for (int c = 0; c < nchunk; ++c) {
+      const float* q = partr + (((long long)b * nchunk + c) * n0 + idx) * 2;
       lse2_merge(m, s, q[0], q[1]);
     }
   } else {
@@ -264,6 +263,197 @@ __global__ __launch_bounds__(256) void dual_softmax_apply_kernel(const float* vb
   if (scores) *(VT*)(scores + o) = pr;
   if (kp) *(VT*)(kp + o) = kk;
   if (fin) *(VT*)(fin + o) = ff;
+}
+
+// ---- dual softmax on the 16-bit matrix cores: split-fp16 correlation ------------------------------------------------
+// BASELINE.json configs[4] names an "fp16 MFMA descriptor correlation"; `final_scores` feeds a sampler and must stay at fp32
+// round-off of the reference's fp32 matmul (feature_matcher.py:65).  Both hold with SPLIT operands: every descriptor entry
+// (|x| <= 1: L2-normalised descriptors, extractor_utils.py:6-10) is scaled by 2^10 (exact; keeps the low part out of fp16's
+// subnormals) and written as hi = rn16(x'), lo = rn16(x' - hi): 22 mantissa bits.  x0.x1 = (hi0 + lo0)(hi1 + lo1) is
+// evaluated as lo0.hi1 + hi0.lo1 + hi0.hi1 -- three v_mfma_f32_32x32x16_f16 passes, every product exact in fp32, fp32
+// accumulation; the dropped lo.lo term is <= 2^-22 |x0||x1| (measured against the fp32 chain: tests/test_kernels_gpu.py).
+// 24 MFMAs of 32 cycles per 32 x 32 tile instead of 64 of 64: the stage is no longer matrix-bound, so
+//   pre    mk split planes: each image side as blocks of 32 keypoints in MFMA-operand order -- block = 8 K-steps x {hi, lo} x
+//          (64 lanes x 16 B): a wave fetches a tile's operands with 16 fully coalesced 1-KiB loads;
+//   pass 1 correlation -> row sums and per-32-row-block column sums of 2^v2 ONLY (no stored correlation: round 3 wrote and
+//          re-read 480 MB at 32 pairs).  |v2| <= inv_T log2(e) is bounded for unit-norm descriptors, so the sums need no
+//          running maximum: one v_exp_f32 per element;
+//   merge  lse_final_kernel as for the exact path (partials carry max = 0);
+//   pass 2 the SAME correlation again (bit-identical accumulators) -> scores, kp_scores, final_scores straight from registers.
+constexpr int SP_KS = 8;        // K steps of 16 channels: C = 128
+constexpr int SP_BLK_U4 = SP_KS * 2 * 64;   // uint4 per block of 32 keypoints (16 KiB)
+constexpr int NCHUNK_S = 8;     // column chunks of the split passes (FIXED: the summation order of a row does not depend on B)
+constexpr float SP_SCALE = 1024.0f;
+
+// fp32 [B, C = 128, n] -> split planes [B, nblk, 8, 2, 64] x 16 B.  grid (nblk, B), 512 threads: thread = (K step, lane)
+__global__ __launch_bounds__(512) void dsc_split_kernel(const float* __restrict__ dsc, uint4* __restrict__ planes, int n, int nblk) {
+  const int blk = blockIdx.x, b = blockIdx.y;
+  const int l = threadIdx.x & 63, st = threadIdx.x >> 6;
+  const int j = blk * 32 + (l & 31), k0 = 16 * st + 8 * (l >> 5);
+  const float* src = dsc + ((long long)b * 128 + k0) * n + j;
+  f16x8 h, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = (j < n ? src[(long long)e * n] : 0.f) * SP_SCALE;
+    const _Float16 xh = (_Float16)x;
+    h[e] = xh;
+    lo[e] = (_Float16)(x - (float)xh);
+  }
+  uint4* o = planes + ((long long)b * nblk + blk) * SP_BLK_U4 + (st * 2) * 64 + l;
+  o[0] = __builtin_bit_cast(uint4, h);
+  o[64] = __builtin_bit_cast(uint4, lo);
+}
+
+struct SplitOperand {
+  uint4 h[SP_KS], l[SP_KS];
+  __device__ __forceinline__ void load(const uint4* __restrict__ blk, int lane) {
+#pragma unroll
+    for (int st = 0; st < SP_KS; ++st) {
+      h[st] = blk[(st * 2) * 64 + lane];
+      l[st] = blk[(st * 2 + 1) * 64 + lane];
+    }
+  }
+};
+
+// S' = 2^20 x (32 rows of a) . (32 columns of b): cross terms first, the large term last
+__device__ __forceinline__ f32x16 corr_split(const SplitOperand& a, const SplitOperand& b) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int st = 0; st < SP_KS; ++st)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.l[st]), __builtin_bit_cast(f16x8, b.h[st]), acc, 0, 0, 0);
+#pragma unroll
+  for (int st = 0; st < SP_KS; ++st)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.h[st]), __builtin_bit_cast(f16x8, b.l[st]), acc, 0, 0, 0);
+#pragma unroll
+  for (int st = 0; st < SP_KS; ++st)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.h[st]), __builtin_bit_cast(f16x8, b.h[st]), acc, 0, 0, 0);
+  return acc;
+}
+
+// pass 1.  grid: decode_unit_grid(gx = row blocks / 4, NCHUNK_S, B); one wave per 32 rows and one chunk of column tiles.
+// partr[((b*NCHUNK_S + chunk)*n0 + row)] = (0, sum_j 2^v2), partc[((b*nrb + rb)*n1 + j)] = (0, sum over the block's rows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lse_split_kernel(
+    const uint4* __restrict__ P0, const uint4* __restrict__ P1, float scale2, float* __restrict__ partr, float* __restrict__ partc,
+    int n0, int n1, int nrb, int ntb, int gx, int nunits) {
+  int bx, by, b;
+  if (!decode_unit_grid(gx, NCHUNK_S, nunits, bx, by, b)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int rb = bx * 4 + wave, i0 = rb * RT;
+  if (rb >= nrb) return;
+  SplitOperand a, bq;
+  a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
+  const int per = (ntb + NCHUNK_S - 1) / NCHUNK_S;
+  const int jt0 = by * per, jt1 = min(ntb, jt0 + per);
+  float rs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+  // rows of this block that exist (the last block is padded with zero descriptors: 2^0 = 1 must not enter a column sum)
+  unsigned rowok = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowok |= (i0 + (r & 3) + 8 * (r >> 2) + 4 * hi < n0 ? 1u : 0u) << r;
+  const uint4* pb = P1 + (long long)b * ntb * SP_BLK_U4;
+  auto tile = [&](const SplitOperand& bt, int jt) {
+    const f32x16 acc = corr_split(a, bt);
+    const int j = jt * RT + l31;
+    const bool jok = j < n1 && jt < jt1;   // (jt == jt1: the spare half of the last loop iteration)
+    float cs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = jok ? __builtin_amdgcn_exp2f(acc[r] * scale2) : 0.f;
+      rs[r] += e;
+      cs += ((rowok >> r) & 1u) ? e : 0.f;
+    }
+    cs += __shfl_xor(cs, 32, 64);   // the other 16 rows of this column live in lane ^ 32
+    if (hi == 0 && jok) {
+      float* o = partc + (((long long)b * nrb + rb) * n1 + j) * 2;
+      o[0] = 0.f;
+      o[1] = cs;
+    }
+  };
+  // two operand sets in flight: the 16 loads of tile jt + 1 are issued before the MFMAs of tile jt (an L2 round trip is as
+  // long as a tile's matrix work, and two waves per SIMD do not hide it).  The loop body is branch-free -- loads past the end
+  // re-read the last tile, the spare tile is masked -- because with a conditional load hipcc's wait-count pass falls back to
+  // vmcnt(0) in front of the first MFMA, i.e. waits for the prefetch it has just issued.
+  SplitOperand bq2;
+  const int last = jt1 - 1;
+  if (jt0 < jt1) {
+    bq.load(pb + (long long)jt0 * SP_BLK_U4, lane);
+    for (int jt = jt0; jt < jt1; jt += 2) {
+      bq2.load(pb + (long long)min(jt + 1, last) * SP_BLK_U4, lane);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch in front of the tile (hipcc sinks it behind the MFMAs to save registers)
+      tile(bq, jt);
+      __builtin_amdgcn_sched_barrier(0);
+      bq.load(pb + (long long)min(jt + 2, last) * SP_BLK_U4, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      tile(bq2, jt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {   // the 32 lanes that share rows (same hi): a fixed butterfly
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) rs[r] += __shfl_xor(rs[r], o, 64);
+  }
+  if (l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row < n0) {
+        float* o = partr + (((long long)b * NCHUNK_S + by) * n0 + row) * 2;
+        o[0] = 0.f;
+        o[1] = rs[r];
+      }
+    }
+  }
+}
+
+// pass 2: the same correlation, outputs from registers.  scores = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores kp
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_split_apply_kernel(
+    const uint4* __restrict__ P0, const uint4* __restrict__ P1, float scale2, const float* __restrict__ scr0,
+    const float* __restrict__ scr1, const float* __restrict__ lse2, float* __restrict__ scores, float* __restrict__ kp,
+    float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits) {
+  int bx, by, b;
+  if (!decode_unit_grid(gx, NCHUNK_S, nunits, bx, by, b)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int rb = bx * 4 + wave, i0 = rb * RT;
+  if (rb >= nrb) return;
+  SplitOperand a, bq;
+  a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
+  const int per = (ntb + NCHUNK_S - 1) / NCHUNK_S;
+  const int jt0 = by * per, jt1 = min(ntb, jt0 + per);
+  float lr[16], s0[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    const int ic = i < n0 ? i : n0 - 1;
+    lr[r] = lse2[((long long)b * 2 + 0) * nmax + ic];
+    s0[r] = scr0 ? scr0[(long long)b * n0 + ic] : 0.f;
+  }
+  const uint4* pb = P1 + (long long)b * ntb * SP_BLK_U4;
+  for (int jt = jt0; jt < jt1; ++jt) {
+    bq.load(pb + (long long)jt * SP_BLK_U4, lane);
+    const f32x16 acc = corr_split(a, bq);
+    const int j = jt * RT + l31;
+    if (j >= n1) continue;
+    const float lc = lse2[((long long)b * 2 + 1) * nmax + j];
+    const float s1 = scr1 ? scr1[(long long)b * n1 + j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (i >= n0) continue;
+      const float v = acc[r] * scale2;
+      const float p = __builtin_amdgcn_exp2f((v - lc) + (v - lr[r]));
+      const float k = s0[r] * s1;
+      const long long o = ((long long)b * n0 + i) * n1 + j;
+      if (scores) scores[o] = p;
+      if (kp) kp[o] = k;
+      if (fin) fin[o] = p * k;
+    }
+  }
 }
 
 // ---- sinkhorn ---------------------------------------------------------------------------------------
@@ -557,7 +747,7 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
     hipLaunchKernelGGL(lse_partial_kernel<false>, g1, dim3(256), 0, st, dsc0, dsc1, scale2, partr, partc, vbuf, C, n0, n1, nrb, gx1, B);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(lse_final_kernel, dim3((nmax + 255) / 256, 2, B), dim3(256), 0, st, partr, partc, lse2, use_dustbin,
-                     dustbin * LOG2E, n0, n1, nmax, nrb);
+                     dustbin * LOG2E, n0, n1, nmax, nrb, NCHUNK);
   MK_CHECK_LAUNCH();
   if (scores || kp_scores || final_scores) {
     // rows of vbuf / outputs start at multiples of n1 floats: 8-byte vectors need n1 even and 8-byte-aligned bases
@@ -569,6 +759,50 @@ int mk_dual_softmax(const float* dsc0, const float* dsc1, const float* scr0, con
     else
       hipLaunchKernelGGL(dual_softmax_apply_kernel<1>, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, vbuf, scr0, scr1, lse2, scores,
                          kp_scores, final_scores, n0, n1, nmax);
+    MK_CHECK_LAUNCH();
+  }
+  return MK_OK;
+}
+
+long long mk_dual_softmax_split_work_floats(int B, int n0, int n1) {
+  const long long nmax = n0 > n1 ? n0 : n1, nrb = (n0 + RT - 1) / RT, ntb = (n1 + RT - 1) / RT;
+  // the two split-plane images (16 KiB per block of 32 keypoints) + row / column partials + log2-sum-exp vectors
+  return (long long)B * (nrb + ntb) * SP_BLK_U4 * 4 + (long long)B * NCHUNK_S * n0 * 2 + (long long)B * nrb * n1 * 2 +
+         (long long)B * 2 * nmax + 8;
+}
+
+int mk_dual_softmax_split(const float* dsc0, const float* dsc1, const float* scr0, const float* scr1, float inv_temperature,
+                          int use_dustbin, float dustbin, float* scores, float* kp_scores, float* final_scores, float* work,
+                          int B, int C, int n0, int n1, mk_stream_t stream) {
+  MK_CHECK_ARG(dsc0 && dsc1 && work, "mk_dual_softmax_split: null pointer");
+  MK_CHECK_ARG(B > 0 && n0 > 0 && n1 > 0 && C == 16 * SP_KS, "mk_dual_softmax_split: C must be %d (use mk_dual_softmax otherwise)", 16 * SP_KS);
+  MK_CHECK_ARG((scr0 && scr1) || (!kp_scores && !final_scores), "mk_dual_softmax_split: kp/final scores need scr0 and scr1");
+  MK_CHECK_ARG(((uintptr_t)work & 15) == 0, "mk_dual_softmax_split: work must be 16-byte aligned");
+  const float LOG2E = 1.4426950408889634f;
+  // unit-norm descriptors: |v2| <= inv_T log2(e); the maximum-free sums of pass 1 need 2^v2 and n 2^v2 inside fp32
+  MK_CHECK_ARG(inv_temperature > 0.f && inv_temperature * LOG2E <= 100.f,
+               "mk_dual_softmax_split: temperature %g too small for the maximum-free sums (use mk_dual_softmax)", 1.0 / inv_temperature);
+  hipStream_t st = (hipStream_t)stream;
+  const int nmax = n0 > n1 ? n0 : n1, nrb = (n0 + RT - 1) / RT, ntb = (n1 + RT - 1) / RT;
+  uint4* P0 = (uint4*)work;
+  uint4* P1 = P0 + (long long)B * nrb * SP_BLK_U4;
+  float* partr = (float*)(P1 + (long long)B * ntb * SP_BLK_U4);
+  float* partc = partr + (long long)B * NCHUNK_S * n0 * 2;
+  float* lse2 = partc + (long long)B * nrb * n1 * 2;
+  hipLaunchKernelGGL(dsc_split_kernel, dim3(nrb, B), dim3(512), 0, st, dsc0, P0, n0, nrb);
+  hipLaunchKernelGGL(dsc_split_kernel, dim3(ntb, B), dim3(512), 0, st, dsc1, P1, n1, ntb);
+  MK_CHECK_LAUNCH();
+  const float scale2 = inv_temperature * LOG2E / (SP_SCALE * SP_SCALE);
+  const int gx = (nrb + 3) / 4;
+  const dim3 g((unsigned)gx * NCHUNK_S * ((B + 7) / 8 * 8));   // see decode_unit_grid
+  hipLaunchKernelGGL(lse_split_kernel, g, dim3(256), 0, st, P0, P1, scale2, partr, partc, n0, n1, nrb, ntb, gx, B);
+  MK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lse_final_kernel, dim3((nmax + 255) / 256, 2, B), dim3(256), 0, st, partr, partc, lse2, use_dustbin,
+                     dustbin * LOG2E, n0, n1, nmax, nrb, NCHUNK_S);
+  MK_CHECK_LAUNCH();
+  if (scores || kp_scores || final_scores) {
+    hipLaunchKernelGGL(dual_softmax_split_apply_kernel, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                       final_scores, n0, n1, nmax, nrb, ntb, gx, B);
     MK_CHECK_LAUNCH();
   }
   return MK_OK;

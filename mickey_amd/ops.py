@@ -230,9 +230,15 @@ def head_tails(f_det, w_score, f_off, w_xy, f_dep, w_dep, f_dsc, nimg, h, w, C, 
     return scr, kps, depth, dsc
 
 
+def dual_softmax_split_ok(C, temperature):
+    """Preconditions of mk_dual_softmax_split that can be checked on the host (the third, |dsc| <= 1, is the caller's)."""
+    return C == 128 and temperature > 0 and LOG2E / float(temperature) <= 100.0
+
+
 def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None, want_scores=True, want_kp=True,
-                 want_final=True):
-    """Returns (scores, kp_scores, final_scores) (None where not requested)."""
+                 want_final=True, split=False):
+    """Returns (scores, kp_scores, final_scores) (None where not requested).  split: the correlation on the 16-bit matrix
+    cores with split-fp16 operands (mk_dual_softmax_split; unit-norm descriptors only), else the exact fp32 MFMA."""
     _chk(dsc0, torch.float32)
     _chk(dsc1, torch.float32)
     B, C, n0 = dsc0.shape
@@ -242,6 +248,11 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
     scores = mk(want_scores)
     kp = mk(want_kp and scr0 is not None)
     fin = mk(want_final and scr0 is not None)
+    if split:
+        work = torch.empty((query("mk_dual_softmax_split_work_floats", B, n0, n1),), device=dev, dtype=torch.float32)
+        call("mk_dual_softmax_split", ptr(dsc0), ptr(dsc1), ptr(scr0), ptr(scr1), 1.0 / float(temperature), int(dustbin is not None),
+             float(dustbin) if dustbin is not None else 0.0, ptr(scores), ptr(kp), ptr(fin), ptr(work), B, C, n0, n1, stream())
+        return scores, kp, fin
     work = torch.empty((query("mk_dual_softmax_work_floats", B, n0, n1, int(scores is None and fin is None)),), device=dev,
                        dtype=torch.float32)
     call("mk_dual_softmax", ptr(dsc0), ptr(dsc1), ptr(scr0), ptr(scr1), 1.0 / float(temperature), int(dustbin is not None),

@@ -180,8 +180,14 @@ def match(W, cfg, dsc0, dsc1, scr0, scr1, lean=False):
     fm = cfg["FEATURE_MATCHER"]
     if fm["TYPE"] == "DualSoftmax":
         ds = fm["DUAL_SOFTMAX"]
+        # AMD.MATCHER_CORR: 'auto' = the split-fp16 correlation on the 16-bit matrix cores when its preconditions hold
+        # (L2-normalised 128-channel descriptors, mickey_hip.h: mk_dual_softmax_split), else the exact fp32 MFMA; 'fp32' | 'split16'
+        mode = str(cfg["AMD"].get("MATCHER_CORR", "auto")).lower()
+        can = bool(cfg["MICKEY"]["DSC_HEAD"]["NORM_DSC"]) and ops.dual_softmax_split_ok(dsc0.shape[1], float(ds["TEMPERATURE"]))
+        if mode == "split16" and not can:
+            raise ValueError("AMD.MATCHER_CORR: split16 needs MICKEY.DSC_HEAD.NORM_DSC, 128 descriptor channels and T >= 0.0145")
         return ops.dual_softmax(dsc0, dsc1, scr0, scr1, float(ds["TEMPERATURE"]), W.dustbin if ds["USE_DUSTBIN"] else None,
-                                want_scores=not lean, want_kp=not lean, want_final=True)
+                                want_scores=not lean, want_kp=not lean, want_final=True, split=can and mode != "fp32")
     if fm["TYPE"] == "Sinkhorn":
         # the reference's Sinkhorn branch is unreachable through featureMatcher.forward; the maths
         # restated is feature_matcher.py:125-137 with matching_mat(dsc0, dsc1, None)

@@ -115,8 +115,10 @@ def test_encoder_gemms_at_bench_size(name, N, K):
         assert float(q[:, :, ntok:].abs().sum()) == 0.0 and float(vt[:, :, :, ntok:].abs().sum()) == 0.0
 
 
-def test_matcher_at_bench_batch_vs_oracle():
-    """Dual-softmax + keypoint product at B = 32, n = 1938 (the XCD-local batched scheduling) against the oracle."""
+@pytest.mark.parametrize("split", [False, True])
+def test_matcher_at_bench_batch_vs_oracle(split):
+    """Dual-softmax + keypoint product at B = 32, n = 1938 (the XCD-local batched scheduling) against the oracle; split: the
+    16-bit-matrix-core correlation the forward takes by default."""
     from mickey_amd import ops
     from oracle import mickey_oracle as O
     dev = _dev()
@@ -126,7 +128,7 @@ def test_matcher_at_bench_batch_vs_oracle():
     d1 = torch.nn.functional.normalize(torch.randn((B, 128, n), generator=g) + 0.7 * d0, dim=1)
     s0 = torch.rand((B, 1, n), generator=g) / n
     s1 = torch.rand((B, 1, n), generator=g) / n
-    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.9)
+    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.9, split=split)
     for b in (0, 7, 31):
         ref = O.dual_softmax(d0[b:b + 1], d1[b:b + 1], 0.9, 0.1)
         kref = torch.matmul(s0[b:b + 1].transpose(2, 1), s1[b:b + 1])

@@ -608,8 +608,10 @@ def test_head_tails():
     assert abs(float(scr.sum()) - nimg) < 1e-4
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n0,n1", [(150, 131), (1938, 1938)])
-def test_dual_softmax_vs_oracle(n0, n1):
+def test_dual_softmax_vs_oracle(n0, n1, split):
+    """split = False: the exact fp32 MFMA correlation; True: split-fp16 operands on the 16-bit matrix cores (mk_dual_softmax_split)."""
     from mickey_amd import ops
     from oracle import mickey_oracle as O
     dev = _dev()
@@ -621,7 +623,7 @@ def test_dual_softmax_vs_oracle(n0, n1):
     s1 = torch.rand((B, 1, n1), generator=g(24)) / n1
     ref = O.dual_softmax(d0, d1, 0.7, 0.1)
     kp_ref = torch.matmul(s0.transpose(2, 1), s1)
-    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.7)
+    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.7, split=split)
     assert rel(sc, ref) < 1e-5, rel(sc, ref)
     assert torch.equal(kp.cpu(), kp_ref)
     assert rel(fin, ref * kp_ref) < 1e-5
@@ -629,9 +631,40 @@ def test_dual_softmax_vs_oracle(n0, n1):
     top2 = ref.topk(2, dim=2).values
     clear = (top2[..., 0] - top2[..., 1]) > 1e-5 * top2[..., 0]
     assert torch.equal(sc.cpu().argmax(2)[clear], ref.argmax(2)[clear])
+    # the same for the column arg-max (the other direction of the mutual-NN check)
+    top2c = ref.topk(2, dim=1).values
+    clearc = (top2c[:, 0] - top2c[:, 1]) > 1e-5 * top2c[:, 0]
+    assert torch.equal(sc.cpu().argmax(1)[clearc], ref.argmax(1)[clearc])
     # no dustbin
-    sc2, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, None, want_kp=False, want_final=False)
+    sc2, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, None, want_kp=False, want_final=False, split=split)
     assert rel(sc2, O.dual_softmax(d0, d1, None, 0.1)) < 1e-5
+    # lean call (final_scores only) == the full call's final_scores, bit for bit
+    _, _, fin2 = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 0.7, want_scores=False, want_kp=False, split=split)
+    assert torch.equal(fin2, fin)
+
+
+def test_split_fp16_correlation_is_fp32_grade():
+    """The split-operand correlation against an fp64 evaluation of the dual softmax, next to the exact-fp32 MFMA path and the
+    oracle's own fp32 matmul: its error must be of the SAME order (the three share the fp32 round-off of the exponent, ~|v2| 6e-8),
+    on unit-norm descriptors with planted near-duplicates (large logits) and with many tiny entries (the lo plane's range)."""
+    from mickey_amd import ops
+    from oracle import mickey_oracle as O
+    dev = _dev()
+    B, n = 2, 700
+    d0 = torch.randn((B, 128, n), generator=g(41))
+    d0[:, 64:] *= 1e-3                                   # half of the channels tiny: hi underflows fp16's normal range unscaled
+    d0 = F.normalize(d0, dim=1)
+    d1 = F.normalize(d0 + 0.05 * torch.randn((B, 128, n), generator=g(42)), dim=1)    # every keypoint has a near-duplicate: S ~ 1
+    ref64 = O.dual_softmax(d0.double(), d1.double(), 1.0, 0.1)
+    errs = {}
+    for name, kw in (("exact", dict(split=False)), ("split", dict(split=True))):
+        sc, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, 1.0, want_kp=False, want_final=False, **kw)
+        errs[name] = rel(sc, ref64)
+        assert torch.equal(sc.cpu().argmax(2), ref64.argmax(2)) and torch.equal(sc.cpu().argmax(1), ref64.argmax(1))
+    errs["oracle_fp32"] = rel(O.dual_softmax(d0, d1, 1.0, 0.1), ref64)
+    print("dual softmax vs fp64:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["split"] < 3e-6 and errs["exact"] < 3e-6
+    assert errs["split"] < 3 * max(errs["exact"], errs["oracle_fp32"])
 
 
 @pytest.mark.parametrize("B,C,n0,n1", [(3, 64, 77, 200), (9, 128, 97, 64), (1, 32, 33, 31)])
@@ -661,8 +694,9 @@ def test_matcher_golden(golden):
     gen = g(21)
     d0 = F.normalize(torch.randn((2, 128, 150), generator=gen), dim=1)
     d1 = F.normalize(torch.randn((2, 128, 131), generator=gen) + 0.5 * d0[:, :, :131], dim=1)
-    sc, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, 0.7, want_kp=False, want_final=False)
-    assert rel(sc, torch.from_numpy(gd["dual_softmax"])) < 1e-5
+    for split in (False, True):
+        sc, _, _ = ops.dual_softmax(d0.to(dev), d1.to(dev), None, None, 0.1, 0.7, want_kp=False, want_final=False, split=split)
+        assert rel(sc, torch.from_numpy(gd["dual_softmax"])) < 1e-5
     sk = ops.sinkhorn(d0.to(dev), d1.to(dev), 1.3, 10)
     assert rel(sk, torch.from_numpy(gd["sinkhorn"])) < 2e-5
     # mutual-NN: bit-exact indices given identical scores
