@@ -72,15 +72,15 @@ def test_branch_vs_oracle_fp32(cfg, branch):
         assert errs[k] <= tol[k], (branch, k, errs[k], tol[k])
     # the branch really was taken: the flipped switch changes the outputs it governs
     base = {k: v.clone() for k, v in batch.items()}
-    with torch.no_grad():
-        base.update(O.compute_correspondences(sd, cfg, base))
+    with torch.no_grad():   # (the default configuration's own state dict: only that one carries the dustbin parameter)
+        base.update(O.compute_correspondences(syn.mickey_state_dict(cfg, seed=0), cfg, base))
     moved = {"sigmoid_detector": "scr0", "depth_sigmoid": "depth_kp0", "raw_descriptors": "dsc0", "no_posenc_kp": "scr0",
              "no_posenc_dsc": "dsc0", "no_posenc": "dsc0", "no_dustbin": "scores", "all_flipped": "scr0"}[branch]
     if branch == "no_dustbin":
-        # the descriptors of this random-weight model are nearly parallel (logits ~ +10 everywhere): the dustbin's 2^(1.44) is
-        # one part in 10^6 of a row sum -- the switch moves `scores` by less than the 1e-4 bound; what is asserted is that the
-        # oracle's two branches differ at all, and (test_kernels_gpu.py::test_dual_softmax_vs_oracle) that the kernel follows
-        # either on descriptors where the dustbin matters
+        # the descriptors of this random-weight model are nearly parallel (logits ~ +10 everywhere): the dustbin's e^1 is one
+        # part in 10^6 of a row sum -- the switch moves `scores` by less than the 1e-4 bound; asserted here: the oracle's two
+        # branches differ at all (test_kernels_gpu.py::test_dual_softmax_vs_oracle covers both branches of the kernel on
+        # descriptors where the dustbin matters)
         assert not torch.equal(odata[moved], base[moved])
     else:
         assert rel(odata[moved], base[moved]) > 1e-3
