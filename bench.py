@@ -297,7 +297,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--heads-dtype", default="auto", choices=["auto", "same", "bf16", "fp16", "fp32"],
+    ap.add_argument("--heads-dtype", default="auto", choices=["auto", "same", "bf16", "fp16", "fp32", "split"],
                     help="AMD.HEADS_DTYPE of the headline model: operand type of the four head stacks (auto = fp16 beside a "
                          "16-bit encoder; the reference runs them in fp32)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA cores")

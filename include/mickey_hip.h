@@ -177,6 +177,23 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
                void* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd, int act, int out_kind, int dtype,
                mk_stream_t stream);
 
+/* The same convolution with SPLIT operands -- fp32-grade products on the 16-bit matrix cores (the reference runs its heads in
+ * fp32, mickey_extractor.py:53-56; the fp32-input MFMA is 1/16 of the 16-bit rate).  Activations and weights are each held as
+ * two fp16 planes, x * s = hi + lo (22 mantissa bits; s a power of two that keeps lo out of fp16's subnormals), and every
+ * product is evaluated as lo.hi + hi.lo + hi.hi: three sweeps of the plain kernel's K loop with fp32 accumulation.
+ *   in1_hi / in1_lo, in2_hi / in2_lo: bordered fp16 feature maps (mk_split_planes of the fp32 maps, scale s_a);
+ *   W: fp16 [Cout, 3 K], K = 9 C1 + C2, = [W_hi | W_lo | W_hi] of the BatchNorm-folded weights times s_w (the HI weights meet
+ *      the LO activations in sweep 0); an identity shortcut is passed as in2 = the block input with identity columns in W;
+ *   out: fp32 [.., Cout], dense rows or (out_bordered) a bordered feature map; acc_scale = 1 / (s_a s_w), applied to the
+ *      accumulators before bias / activation. */
+int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
+                     long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
+                     long long strideBias, float* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd,
+                     int act, int out_bordered, float acc_scale, mk_stream_t stream);
+
+/* fp32 [n] -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504).  n % 4 == 0. */
+int mk_split_planes(const float* src, long long n, float scale, void* hi, void* lo, mk_stream_t stream);
+
 /* Start of Transformer_self_att (att_layers/transformer.py:92-95): xs = x + pe (fp32 stream) and an
  * lp copy into columns [0,C) of a [rows, ld_cat] buffer.  x lp [G][rows, C]; pe fp32 [npix, C] or NULL. */
 int mk_posenc_add(const void* x, const float* pe, float* xs, void* cat, int ld_cat, int groups, int nimg, int npix, int C,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_bordered_rows": ("l", "iii"),
     "mk_conv3x3": ("i", "pliplipilplplpiliiiiiiip"),
+    "mk_conv3x3_split": ("i", "pplipplipilplpiliiiiiifp"),
+    "mk_split_planes": ("i", "plfppp"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
     "mk_linattn_work_floats": ("l", "iiii"),
     "mk_linattn_kv": ("i", "pppiiiip"),

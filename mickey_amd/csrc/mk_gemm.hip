@@ -344,4 +344,53 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
   return launch<A_CONV3>(p, groups, dtype, (hipStream_t)stream);
 }
 
+// fp32 -> two fp16 planes, x * scale = hi + lo (22 mantissa bits); |x * scale| is saturated at fp16's largest finite value
+namespace {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long n4, float scale,
+                                                           uint2* __restrict__ hi, uint2* __restrict__ lo) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 x = __builtin_nontemporal_load((const f32x4*)src + i) * scale;
+  f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float v = fminf(fmaxf(x[e], -65504.f), 65504.f);
+    h[e] = (_Float16)v;
+    l[e] = (_Float16)(v - (float)h[e]);
+  }
+  hi[i] = __builtin_bit_cast(uint2, h);
+  lo[i] = __builtin_bit_cast(uint2, l);
+}
+}  // namespace
+
+int mk_split_planes(const float* src, long long n, float scale, void* hi, void* lo, mk_stream_t stream) {
+  MK_CHECK_ARG(src && hi && lo && n > 0 && n % 4 == 0, "mk_split_planes: need n %% 4 == 0 and non-null pointers");
+  MK_CHECK_ARG((((uintptr_t)src | (uintptr_t)hi * 2 | (uintptr_t)lo * 2) & 15) == 0, "mk_split_planes: src must be 16-byte, planes 8-byte aligned");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n4, scale,
+                     (uint2*)hi, (uint2*)lo);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
+                     long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
+                     long long strideBias, float* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd,
+                     int act, int out_bordered, float acc_scale, mk_stream_t stream) {
+  GemmParams p = {};
+  p.A = in1_hi; p.A_lo = in1_lo; p.A2 = in2_hi; p.A2_lo = in2_lo; p.W = W;
+  p.npass = 3; p.acc_scale = acc_scale;
+  p.M = nimg * H * Wd; p.N = Cout; p.K = 3 * (9 * C1 + (in2_hi ? C2 : 0));
+  p.ldw = ldw; p.strideA_g = stride_in1; p.strideA2_g = stride_in2; p.strideW_g = strideW;
+  p.strideBias_g = strideBias; p.strideOut_g = strideOut;
+  p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2_hi ? C2 : 0;
+  p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout;
+  p.out_f32 = out; p.bord_out = out_bordered ? 1 : 0;
+  if (int e = check_common(p, MK_F16)) return e;
+  MK_CHECK_ARG(in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");
+  MK_CHECK_ARG(C1 % BK == 0 && (!in2_hi || C2 % BK == 0), "mk_conv3x3_split: channel counts must be multiples of the K tile (%d)", BK);
+  MK_CHECK_ARG(out && groups > 0 && nimg > 0 && H > 0 && Wd > 0, "mk_conv3x3_split: bad args");
+  return launch<A_CONV3>(p, groups, MK_F16, (hipStream_t)stream);
+}
+
 }  // extern "C"

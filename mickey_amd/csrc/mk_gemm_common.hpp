@@ -22,7 +22,15 @@ struct GemmParams {
   long long strideA_g, strideA2_g, strideW_g;  // element strides per group (blockIdx.y)
   // conv geometry
   int H, Wd, C1, C2;   // image grid, channels of source 1 / source 2
-  int bord_out;        // conv: the 16-bit output is written in the bordered layout too (it feeds the next conv)
+  int bord_out;        // conv: the output is written in the bordered layout too (it feeds the next conv)
+  // conv with SPLIT operands (mk_conv3x3_split): x = hi + lo 16-bit planes of activations and weights, the product evaluated
+  // as lo.hi + hi.lo + hi.hi -- npass = 3 sweeps over the same K range (9 C1 + C2 each): sweep 0 reads the LO activation
+  // planes (A_lo, A2_lo), sweeps 1 and 2 the HI planes (A, A2); W holds [W_hi | W_lo | W_hi] along K.  acc_scale undoes the
+  // power-of-two scaling of the planes in the epilogue (1.0f = plain conv: no multiply is issued).
+  const void* A_lo;
+  const void* A2_lo;
+  int npass;           // 0 / 1: plain; 3: split operands
+  float acc_scale;
   // epilogue
   int epi;
   int act;
@@ -263,6 +271,8 @@ template <typename T, int AMODE, int NW, int AJ, int WJ>
 struct Stager {
   const T* A;
   const T* A2;
+  const T* Alo;    // split-operand conv: the LO planes (sweep 0)
+  const T* A2lo;
   const T* wrow[WJ];
   long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: bordered row of the pixel
   int wave, srow, sp;
@@ -273,6 +283,8 @@ struct Stager {
     sp = lane & 7;
     A = (const T*)p.A + (long long)g * p.strideA_g;
     A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
+    Alo = p.A_lo ? (const T*)p.A_lo + (long long)g * p.strideA_g : nullptr;
+    A2lo = p.A2_lo ? (const T*)p.A2_lo + (long long)g * p.strideA2_g : nullptr;
     const T* W = (const T*)p.W + (long long)g * p.strideW_g;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -297,19 +309,31 @@ struct Stager {
 #pragma unroll
       for (int j = 0; j < AJ; ++j) glds16(A + aoff[j] + k0, sA + (wave * AJ + j) * 1024);
     } else {
-      // wave-uniform: which source / tap does this K tile belong to
+      // wave-uniform: which sweep (split operands) / source / tap does this K tile belong to
       const int kc = 9 * p.C1;
+      int kk = k0;
+      bool lo = false;
+      if (p.npass > 1) {
+        const int kp = kc + p.C2, sweep = k0 / kp;
+        kk = k0 - sweep * kp;
+        lo = sweep == 0;
+      }
+      // (the four plane pointers as values first: a select between two MEMBER loads keeps the whole Stager in scratch)
+      const T* const s1h = A;
+      const T* const s1l = Alo;
+      const T* const s2h = A2;
+      const T* const s2l = A2lo;
       const T* src;
       int cs, c0, shift = 0;   // shift: the tap in bordered rows (out-of-image taps land on zero border rows)
-      if (k0 < kc) {
-        const int tap = k0 / p.C1;
-        c0 = k0 - tap * p.C1;
+      if (kk < kc) {
+        const int tap = kk / p.C1;
+        c0 = kk - tap * p.C1;
         shift = (tap / 3 - 1) * (p.Wd + 1) + tap % 3 - 1;
-        src = A;
+        src = lo ? s1l : s1h;
         cs = p.C1;
       } else {
-        c0 = k0 - kc;
-        src = A2;
+        c0 = kk - kc;
+        src = lo ? s2l : s2h;
         cs = p.C2;
       }
 #pragma unroll
@@ -419,6 +443,11 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
       const int n = nb + ni * 16;
       if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
       f32x4 v = acc[mi][ni];
+      if (EPI == MK_EPI_STORE && p.npass > 1) {   // split-operand conv: undo the planes' power-of-two scaling
+        const float sc = p.acc_scale;             // (element-wise: `v *= p.acc_scale` keeps a slice of GemmParams in scratch)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= sc;
+      }
       if (LN) v = v * prm.x + (cs[ni] * prm.y + bv[ni]);
       else if (HAS_BIAS) v += bv[ni];
       if (EPI == MK_EPI_STORE) {
@@ -434,7 +463,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
           v = gelu_erf4(v);
         }
         if (p.out_f32) {
-          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = v;
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (p.bord_out ? brow : (long long)m) * p.ldc + n) = v;
         } else {
           V4 o;
 #pragma unroll
@@ -698,6 +727,11 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           f32x4 v = acc[half * 4 + mi][ni];
+          if (CONV && p.npass > 1) {   // split-operand conv: undo the planes' power-of-two scaling
+            const float sc = p.acc_scale;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= sc;
+          }
           if (HAS_BIAS && !SPLIT) v += bv[ni];
           if (EPI == MK_EPI_STORE) {
             if (CONV && p.resid_lp) {
@@ -738,11 +772,17 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
       if (ok && c == 0) ((float2*)p.stats_out)[xrow * p.nslot_out + (nw >> 6)] = make_float2(ssum, qsum);
     };
     auto drain = [&](int half, int it0 = 0, int it1 = 16) {
+      // conv output that feeds the next conv (split-operand mode: fp32 rows, re-split by mk_split_planes): bordered rows
+      const bool bordf = CONV && p.bord_out;
+      BorderedRow bwf;
+      if (bordf) bwf.init(mw + half * 64 + it0 * 4 + rr, p.H, p.Wd);
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         if (it < it0 || it >= it1) continue;
         const int r = it * 4 + rr;
         const int m = mw + half * 64 + r;
+        const int extraf = bordf ? bwf.extra : 0;
+        if (bordf) bwf.step(4, p.H, p.Wd);
         f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
         if (SPLIT) val += bvd;
         const bool ok = SPLIT || (m < p.M && n < p.N);   // SPLIT: interior tiles only
@@ -770,7 +810,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           if (SPLIT) emit_row(xrow, (T*)p.xh + xrow * p.ldxs + n, (T*)p.xl + xrow * p.ldxs + n, x, ok);
           else if (ok) *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
         } else {
-          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (long long)m * p.ldc + n) = val;
+          *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + ((long long)m + extraf) * p.ldc + n) = val;
         }
       }
     };

@@ -70,14 +70,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // conv: A stages are issued in K order (0, 1, 2, ...), so where the NEXT stage reads -- source, 3x3 tap, first channel,
   // folded into one wave-uniform base pointer -- is running scalar state, advanced once per stage.  K = 9 taps x C1 channels of source 1, then C2 channels of source 2
   // (the 1x1 shortcut) at the pixel itself.
-  const T* cbase = AMODE == A_DENSE ? A : A - (long long)(p.Wd + 2) * p.C1;   // tap (-1, -1), channel 0
+  // Split operands (p.npass == 3, mk_conv3x3_split): the K range is swept three times -- sweep 0 over the LO activation
+  // planes, sweeps 1 and 2 over the HI planes (W holds [W_hi | W_lo | W_hi] along K, so the W side just keeps streaming).
+  const bool split = AMODE != A_DENSE && p.npass > 1;
+  const T* Acur = split ? (const T*)p.A_lo + (long long)g * p.strideA_g : A;
+  const T* A2cur = split && p.A2_lo ? (const T*)p.A2_lo + (long long)g * p.strideA2_g : A2;
+  const int ntap = A2 ? 10 : 9;   // K segments of one sweep: nine taps (+ the shortcut source)
+  const T* cbase = AMODE == A_DENSE ? A : Acur - (long long)(p.Wd + 2) * p.C1;   // tap (-1, -1), channel 0
   int cleft = p.C1, ctap = 0;
   auto conv_advance = [&]() {
     cleft -= BK;
     const bool wrap = cleft == 0;
     ctap += wrap ? 1 : 0;
+    if (wrap && ctap == ntap) {   // end of a sweep (only the split form goes on from here): HI planes from now on
+      ctap = 0;
+      Acur = A;
+      A2cur = A2;
+    }
     const int ty = (ctap * 11) >> 5, tx = ctap - 3 * ty;   // ctap / 3, ctap % 3 for 0 <= ctap < 9
-    const T* tapbase = ctap < 9 ? A + (long long)((ty - 1) * (p.Wd + 1) + tx - 1) * p.C1 : A2;
+    const T* tapbase = ctap < 9 ? Acur + (long long)((ty - 1) * (p.Wd + 1) + tx - 1) * p.C1 : A2cur;
     cbase = wrap ? tapbase : cbase + BK;
     cleft = wrap ? (ctap < 9 ? p.C1 : p.C2) : cleft;
   };

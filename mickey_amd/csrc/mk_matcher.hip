@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto tile = [&](const SplitOperand& bt, int jt) {
     const f32x16 acc = corr_split(a, bt);
     const int j = jt * RT + l31;
-    const bool jok = j < n1 && jt < jt1;   // (jt == jt1: the spare half of the last loop iteration)
+    const bool jok = j < n1;
     float cs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -373,24 +373,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       o[1] = cs;
     }
   };
-  // two operand sets in flight: the 16 loads of tile jt + 1 are issued before the MFMAs of tile jt (an L2 round trip is as
-  // long as a tile's matrix work, and two waves per SIMD do not hide it).  The loop body is branch-free -- loads past the end
-  // re-read the last tile, the spare tile is masked -- because with a conditional load hipcc's wait-count pass falls back to
-  // vmcnt(0) in front of the first MFMA, i.e. waits for the prefetch it has just issued.
-  SplitOperand bq2;
-  const int last = jt1 - 1;
-  if (jt0 < jt1) {
-    bq.load(pb + (long long)jt0 * SP_BLK_U4, lane);
-    for (int jt = jt0; jt < jt1; jt += 2) {
-      bq2.load(pb + (long long)min(jt + 1, last) * SP_BLK_U4, lane);
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch in front of the tile (hipcc sinks it behind the MFMAs to save registers)
-      tile(bq, jt);
-      __builtin_amdgcn_sched_barrier(0);
-      bq.load(pb + (long long)min(jt + 2, last) * SP_BLK_U4, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      tile(bq2, jt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  // (a second operand set in flight -- the loads of tile jt + 1 in front of the MFMAs of tile jt -- needs 128 more registers
+  // than two waves per SIMD leave: hipcc spills; as written it issues the next tile's loads as the current tile's operand
+  // registers die, and the other wave of the SIMD covers the rest of the L2 round trip)
+  for (int jt = jt0; jt < jt1; ++jt) {
+    bq.load(pb + (long long)jt * SP_BLK_U4, lane);
+    tile(bq, jt);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {   // the 32 lanes that share rows (same hi): a fixed butterfly

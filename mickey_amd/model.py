@@ -40,17 +40,27 @@ def resolve_heads_dtype(cfg, encoder_dtype):
     'auto': fp16 beside a 16-bit encoder -- the heads' activations are BatchNorm outputs and the encoder's final-norm tokens
     (which the reference's shipped fp16 mode itself holds in fp16, mickey_extractor.py:49-51), fp16's 11 bits run at the bf16
     MFMA rate and take the heads' share of the bf16 mode's noise down 8x; fp32 beside the fp32 parity encoder.
-    'same' = the encoder's type, or bf16 | fp16 | fp32 (exact: fp32 MFMA)."""
+    'same' = the encoder's type, or bf16 | fp16 | fp32 (exact: fp32 MFMA) | split (the fp32 pipeline with its 3x3 convolutions
+    on split fp16 operands: fp32-grade products on the 16-bit matrix cores, resolve_heads_split)."""
     v = str(cfg["AMD"].get("HEADS_DTYPE", "auto")).lower()
+    if v == "split":
+        return torch.float32
     if v == "auto":
         return torch.float32 if encoder_dtype == torch.float32 else torch.float16
     if v == "same":
         return encoder_dtype
     if v not in _LP:
-        raise ValueError("AMD.HEADS_DTYPE must be auto | same | bf16 | fp16 | fp32, got %r" % v)
+        raise ValueError("AMD.HEADS_DTYPE must be auto | same | bf16 | fp16 | fp32 | split, got %r" % v)
     if encoder_dtype == torch.float32 and _LP[v] != torch.float32:
         raise ValueError("AMD.HEADS_DTYPE: %s needs a 16-bit AMD.ENCODER_DTYPE (the fp32 parity mode runs everything in fp32)" % v)
     return _LP[v]
+
+
+def resolve_heads_split(cfg):
+    """AMD.HEADS_DTYPE: split -- the reference's precision split (fp32 heads behind a 16-bit encoder, mickey_extractor.py:49-56)
+    at 16-bit matrix-core speed: head activations, LayerNorms and the small linears as in the fp32 mode, the 3x3
+    convolutions (99 % of the heads' flops) as three fp16 MFMA passes over hi / lo operand planes (mk_conv3x3_split)."""
+    return str(cfg["AMD"].get("HEADS_DTYPE", "auto")).lower() == "split"
 
 
 class _SolverView:
@@ -101,6 +111,7 @@ class MickeyRelativePose(nn.Module):
         amd = self.cfg["AMD"]
         self.lp_dtype = resolve_encoder_dtype(self.cfg)
         self.heads_dtype = resolve_heads_dtype(self.cfg, self.lp_dtype)
+        self.heads_split = resolve_heads_split(self.cfg)
         self.lean = bool(amd.get("LEAN", False))
         self.ln_fold = bool(amd.get("LN_FOLD", True))   # norm1 / norm2 folded into the GEMMs around them (16-bit modes)
         self.ln_centre = bool(amd.get("LN_CENTRE", True))   # ... with the residual stream kept row-centred
@@ -228,7 +239,7 @@ class MickeyRelativePose(nn.Module):
             if fm["TYPE"] == "DualSoftmax" and fm["DUAL_SOFTMAX"]["USE_DUSTBIN"] and DUSTBIN_KEY not in self._sd:
                 raise RuntimeError("FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN is set but the checkpoint has no %s (the "
                                    "reference's strict load fails on this too)" % DUSTBIN_KEY)
-            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_dtype=self.heads_dtype,
+            self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_dtype=self.heads_dtype, heads_split=self.heads_split,
                                                 ln_fold=self.ln_fold, ln_centre=self.ln_centre)
         return self._dev_weights
 

@@ -199,6 +199,29 @@ def conv3x3(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=N
     return out
 
 
+SPLIT_ACT_SCALE, SPLIT_W_SCALE = 64.0, 1024.0   # powers of two: activations up to 1023, weights up to 63 stay finite in fp16
+
+
+def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
+    """fp32 tensor -> fp16 planes with x * scale = hi + lo (mk_split_planes); hi / lo: preallocated, same shape."""
+    assert x.dtype == torch.float32 and hi.dtype == torch.float16 and lo.dtype == torch.float16
+    assert x.is_contiguous() and hi.is_contiguous() and lo.is_contiguous() and hi.shape == x.shape == lo.shape
+    call("mk_split_planes", ptr(x), x.numel(), float(scale), ptr(hi), ptr(lo), stream())
+    return hi, lo
+
+
+def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, stride_in1=0, stride_in2=0,
+                  stride_w=0, stride_bias=0, stride_out=0, out_bordered=False):
+    """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes, w fp16 [.., Cout, 3 K], out fp32."""
+    assert out.dtype == torch.float32 and w.dtype == torch.float16
+    h1, l1 = in1
+    h2, l2 = in2 if in2 is not None else (None, None)
+    call("mk_conv3x3_split", ptr(h1), ptr(l1), stride_in1, C1, ptr(h2), ptr(l2), stride_in2, C2, ptr(w), w.shape[-1], stride_w,
+         ptr(bias), stride_bias, ptr(out), Cout, stride_out, groups, nimg, H, W, act, int(out_bordered),
+         1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), stream())
+    return out
+
+
 def posenc_add(x, pe, xs, cat, groups, nimg, npix, C):
     call("mk_posenc_add", ptr(x), ptr(pe), ptr(xs), ptr(cat), cat.stride(-2), groups, nimg, npix, C, dtype_code(x.dtype),
          stream())

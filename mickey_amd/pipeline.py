@@ -108,17 +108,37 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     mk = cfg["MICKEY"]
     R = ops.bordered_rows(nimg, gh, gw)
     geo = "_%d_%d_%d" % (nimg, gh, gw)   # bordered buffers: the workspace key carries the geometry (see encoder_forward)
+    split = bool(getattr(W, "heads_split", False))   # 3x3 convs on split fp16 operands inside the fp32 head pipeline
+
+    def planes(name, x):
+        """fp32 (bordered) activation -> its (hi, lo) fp16 planes, the operand form of mk_conv3x3_split; border rows are
+        zeros in x, hence in both planes."""
+        hi = ws.get(name + "_hi" + geo, tuple(x.shape), torch.float16, dev)
+        lo = ws.get(name + "_lo" + geo, tuple(x.shape), torch.float16, dev)
+        return ops.split_planes(x, hi, lo)
+
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
+    xp = planes("feat", feat) if split else None
     for bi, rb in enumerate(W.rb):
         co = rb.cout
         last = bi == len(W.rb) - 1   # its output feeds the attention layers (row-wise kernels): dense rows
         h1 = ws.get("rb%d_h" % bi + geo, (G, R, co), lp, dev, zero=True)
-        ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
-                    stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
         xo = ws.get("rb%d_x" % bi + geo, (G, M if last else R, co), lp, dev, zero=not last)
-        ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=x_in, C2=c_in,
-                    stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
-                    stride_out=(M if last else R) * co, out_bordered=not last)
+        if split:
+            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
+                              stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
+            hp = planes("rb%d_h" % bi, h1)
+            ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in,
+                              stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
+                              stride_out=(M if last else R) * co, out_bordered=not last)
+            if not last:
+                xp = planes("rb%d_x" % bi, xo)
+        else:
+            ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
+                        stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
+            ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=x_in, C2=c_in,
+                        stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
+                        stride_out=(M if last else R) * co, out_bordered=not last)
         x_in, c_in, s_in = xo, co, R * co
     C = c_in  # 128
     # ---- Transformer_self_att: 3 linear-attention encoder layers, residual stream in fp32 ----
@@ -156,19 +176,31 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout
     h4 = ws.get("rb4_h" + geo, (3, R, ck), lp, dev, zero=True)
-    ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
-                stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
     f4 = ws.get("rb4_f", (3, M, ck), torch.float32, dev)
-    ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
-                in2=x4 if kpw.has_sc else None, C2=C, resid=None if kpw.has_sc else x4, stride_in1=R * ck,
-                stride_in2=R * C, stride_resid=R * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck,
-                stride_out=M * ck)
     cd = dw.cout
     hd = ws.get("rb4_hd" + geo, (R, cd), lp, dev, zero=True)
-    ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
-    ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246
-                in2=x4[3] if dw.has_sc else None, C2=C, resid=None if dw.has_sc else x4[3])
+    if split:
+        x4h, x4l = planes("att_out", x4)
+        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
+                          stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
+        assert kpw.has_sc and dw.has_sc   # (weights.prepare gives the descriptor block identity shortcut columns in this mode)
+        ops.conv3x3_split(planes("rb4_h", h4), ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
+                          in2=(x4h[:3], x4l[:3]), C2=C, stride_in1=R * ck, stride_in2=R * C,
+                          stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
+        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
+        ops.conv3x3_split(planes("rb4_hd", hd), cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,
+                          in2=(x4h[3], x4l[3]), C2=C)   # relu=False, mickey_extractor.py:246
+    else:
+        ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
+                    stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
+        ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
+                    in2=x4 if kpw.has_sc else None, C2=C, resid=None if kpw.has_sc else x4, stride_in1=R * ck,
+                    stride_in2=R * C, stride_resid=R * C, stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck,
+                    stride_out=M * ck)
+        ops.conv3x3(x4[3], C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
+        ops.conv3x3(hd, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,   # relu=False, mickey_extractor.py:246
+                    in2=x4[3] if dw.has_sc else None, C2=C, resid=None if dw.has_sc else x4[3])
     kh = mk["KP_HEADS"]
     return ops.head_tails(f4[0], W.w_score, f4[1], W.w_xy, f4[2], W.w_depth, fd, nimg, gh, gw, ck, cd, border=3,
                           use_softmax=bool(kh["USE_SOFTMAX"]), use_depth_sigmoid=bool(kh["USE_DEPTHSIGMOID"]),

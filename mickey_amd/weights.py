@@ -104,12 +104,30 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True):
+def split_conv_weight(w, scale=1024.0):
+    """[.., Cout, K] fp32 (BatchNorm folded) -> fp16 [.., Cout, 3 K] = [W_hi | W_lo | W_hi] of w * scale, w * scale = hi + lo:
+    the K layout mk_conv3x3_split sweeps (sweep 0 pairs the LO activation planes with W_hi, 1: hi x lo, 2: hi x hi)."""
+    ws = w.float() * scale
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo, hi], -1)
+
+
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True, heads_split=False):
     """heads_dtype: operand type of the four head stacks (None = lp_dtype; torch.float32 = as the reference, which always
-    runs them in fp32, mickey_extractor.py:53-56) while the encoder uses lp_dtype."""
+    runs them in fp32, mickey_extractor.py:53-56) while the encoder uses lp_dtype.  heads_split (with heads_dtype fp32): the
+    3x3 convolutions -- 99 % of the heads' flops -- run on the 16-bit matrix cores with split fp16 operands
+    (mk_conv3x3_split: fp32-grade products, three MFMA passes), everything else of the heads stays on the fp32 path."""
     W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold, ln_centre=ln_centre)
     dev = device
     W.lp_heads = lp_dtype if heads_dtype is None else heads_dtype
+    W.heads_split = bool(heads_split)
+    assert not W.heads_split or W.lp_heads == torch.float32, "split-operand convs sit in the fp32 head pipeline"
+
+    def convw(t):   # weights of a 3x3 conv (+ shortcut columns): operand type of the heads, or the split K layout
+        if W.heads_split:
+            return split_conv_weight(t).to(device=dev).contiguous()
+        return t.to(device=dev, dtype=W.lp_heads).contiguous()
 
     def lp(t):
         return t.to(device=dev, dtype=W.lp_heads).contiguous()
@@ -124,25 +142,28 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
         folded = [fold_basic_block(sd, e + h + ".resblock%d." % b) for h in HEADS]
         assert all(f[4] for f in folded), "resblock1-3 change the channel count, so all have a 1x1 shortcut"
         blk = DeviceWeights()
-        blk.w1 = lp(torch.stack([f[0] for f in folded]))
+        blk.w1 = convw(torch.stack([f[0] for f in folded]))
         blk.b1 = f32(torch.stack([f[1] for f in folded]))
-        blk.w2 = lp(torch.stack([f[2] for f in folded]))
+        blk.w2 = convw(torch.stack([f[2] for f in folded]))
         blk.b2 = f32(torch.stack([f[3] for f in folded]))
         blk.cout = blk.w1.shape[1]
-        blk.cin = blk.w1.shape[2] // 9
+        blk.cin = folded[0][0].shape[1] // 9
         W.rb.append(blk)
     # resblock4: three keypoint heads (128 -> 64, shortcut) and the descriptor head (128 -> 128, identity)
     kp = [fold_basic_block(sd, e + h + ".resblock4.") for h in HEADS[:3]]
     W.rb4_kp = DeviceWeights()
-    W.rb4_kp.w1, W.rb4_kp.b1 = lp(torch.stack([f[0] for f in kp])), f32(torch.stack([f[1] for f in kp]))
-    W.rb4_kp.w2, W.rb4_kp.b2 = lp(torch.stack([f[2] for f in kp])), f32(torch.stack([f[3] for f in kp]))
+    W.rb4_kp.w1, W.rb4_kp.b1 = convw(torch.stack([f[0] for f in kp])), f32(torch.stack([f[1] for f in kp]))
+    W.rb4_kp.w2, W.rb4_kp.b2 = convw(torch.stack([f[2] for f in kp])), f32(torch.stack([f[3] for f in kp]))
     W.rb4_kp.cout = W.rb4_kp.w1.shape[1]
     W.rb4_kp.has_sc = kp[0][4]
     ds = fold_basic_block(sd, e + "dsc_head.resblock4.")
     W.rb4_dsc = DeviceWeights()
-    W.rb4_dsc.w1, W.rb4_dsc.b1, W.rb4_dsc.w2, W.rb4_dsc.b2 = lp(ds[0]), f32(ds[1]), lp(ds[2]), f32(ds[3])
+    w2d, has_sc = ds[2], ds[4]
+    if W.heads_split and not has_sc:   # identity shortcut as identity columns: the split sweeps then carry the block input too
+        w2d, has_sc = torch.cat([w2d, torch.eye(w2d.shape[0])], 1), True
+    W.rb4_dsc.w1, W.rb4_dsc.b1, W.rb4_dsc.w2, W.rb4_dsc.b2 = convw(ds[0]), f32(ds[1]), convw(w2d), f32(ds[3])
     W.rb4_dsc.cout = ds[0].shape[0]
-    W.rb4_dsc.has_sc = ds[4]
+    W.rb4_dsc.has_sc = has_sc
     # linear-attention stacks
     W.att = []
     for l in range(3):

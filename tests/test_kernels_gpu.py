@@ -548,6 +548,66 @@ def test_conv3x3_big_tiles_and_tiny_grids(nimg, H, W):
     assert rel(out2, ref2.permute(0, 2, 3, 1).reshape(M, Cout)) < 2e-5
 
 
+@pytest.mark.parametrize("nimg,H,W,G,C1,C2,Cout,bordered", [(2, 9, 7, 3, 128, 64, 192, True),     # 128x128 tiles, shortcut source
+                                                            (2, 9, 7, 2, 64, 0, 64, False),       # no second source, dense rows
+                                                            (32, 51, 38, 1, 64, 64, 256, True),   # 256x256 ping-pong tiles
+                                                            (32, 51, 38, 2, 64, 0, 320, False)])
+def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
+    """mk_conv3x3_split: fp32 activations / weights as fp16 hi + lo planes, three MFMA sweeps -- against an fp64 evaluation of
+    the SAME fp32 values its error must be that of an fp32 evaluation (beside it), far below one fp16 rounding (2^-11 =
+    4.9e-4).  Activations carry a wide range of magnitudes (the lo plane's subnormal end) and exact zeros (post-ReLU); both
+    kernels (128x128 and the 256x256 ping-pong), shared / per-group sources, dense and bordered fp32 output.  The references
+    are im2col matmuls on the GPU (fp64 / fp32)."""
+    from mickey_amd import ops, weights
+    dev = _dev()
+    ops.gemm_set_tile(0)
+    M = nimg * H * W
+    x = torch.randn((G, M, C1), generator=g(1)) * torch.exp(1.5 * torch.randn((G, M, 1), generator=g(11)))
+    x = F.relu(x).clamp_(max=900.0).to(dev)
+    x2 = (torch.randn((M, C2), generator=g(2)) * 3.0).to(dev) if C2 else None
+    wc = torch.randn((G, Cout, C1, 3, 3), generator=g(3)) / math.sqrt(9 * C1)
+    wsc = torch.randn((G, Cout, C2), generator=g(4)) / math.sqrt(C2) if C2 else None
+    bias = torch.randn((G, Cout), generator=g(5)).to(dev)
+    w2d = wc.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9 * C1)
+    if C2:
+        w2d = torch.cat([w2d, wsc], 2)
+    K = w2d.shape[2]
+    wsplit = weights.split_conv_weight(w2d).to(dev).contiguous()
+    assert wsplit.shape == (G, Cout, 3 * K) and wsplit.dtype == torch.float16
+    R = ops.bordered_rows(nimg, H, W)
+    xb = _to_bordered(x, nimg, H, W)                         # fp32 [G, R, C1]
+    xh, xl = ops.split_planes(xb, torch.empty_like(xb, dtype=torch.float16), torch.empty_like(xb, dtype=torch.float16))
+    resid = (xh.double() + xl.double() - xb.double() * ops.SPLIT_ACT_SCALE).abs().max()
+    assert float(resid) <= 2.0 ** -21 * float(xb.max()) * ops.SPLIT_ACT_SCALE + 1e-7, float(resid)
+    in2 = None
+    if C2:
+        x2b = _to_bordered(x2, nimg, H, W)
+        in2 = ops.split_planes(x2b, torch.empty_like(x2b, dtype=torch.float16), torch.empty_like(x2b, dtype=torch.float16))
+    out = torch.full((G, R if bordered else M, Cout), 7.0, device=dev, dtype=torch.float32)
+    ops.conv3x3_split((xh, xl), C1, wsplit, bias, out, Cout, G, nimg, H, W, act=ops.ACT_RELU, in2=in2, C2=C2,
+                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 3 * K, stride_bias=Cout, stride_out=out.shape[1] * Cout,
+                      out_bordered=bordered)
+    if bordered:
+        idx = ops.bordered_index(nimg, H, W, dev)
+        mask = torch.ones(R, dtype=torch.bool, device=dev)
+        mask[idx] = False
+        assert bool((out[:, mask] == 7.0).all())
+        out = out[:, idx]
+    worst = 0.0
+    for gi in range(G):
+        xp = F.pad(x[gi].reshape(nimg, H, W, C1), (0, 0, 1, 1, 1, 1))
+        cols = torch.cat([xp[:, ky:ky + H, kx:kx + W].reshape(M, C1) for ky in range(3) for kx in range(3)] + ([x2] if C2 else []), 1)
+        wg = w2d[gi].to(dev)
+
+        def ref(dt):
+            return F.relu(cols.to(dt) @ wg.to(dt).t() + bias[gi].to(dt))
+        ref64 = ref(torch.float64)
+        e_split, e_f32 = rel(out[gi], ref64), rel(ref(torch.float32), ref64)
+        worst = max(worst, e_split)
+        assert e_split < 2e-6 and e_split < 4 * e_f32 + 2e-7, (gi, e_split, e_f32)
+    print("split conv vs fp64: %.2e" % worst)
+
+
 def test_grouped_gemm():
     from mickey_amd import ops
     dev = _dev()

@@ -110,6 +110,29 @@ def test_full_forward_golden(golden, cfg, dtype, heads):
     assert torch.isfinite(data["inliers"]).all()
 
 
+def test_heads_split_equals_heads_fp32(golden, cfg):
+    """AMD.HEADS_DTYPE: split -- the reference's precision split (fp16 ViT, fp32 heads) with the heads' 3x3 convolutions on
+    split fp16 operands: same encoder, same fp32 head pipeline, so it must reproduce the exact-fp32-heads forward to fp32
+    round-off (the three-sweep products are fp32-grade), and with it sit inside the reference's own fp16 floor."""
+    dev = _dev()
+    from mickey_amd import synthetic as syn
+    g = golden("full_forward")
+    batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
+    outs = {}
+    for heads in ("fp32", "split"):
+        model, _ = _model(cfg, "fp16", HEADS_DTYPE=heads)
+        data = {k: v.to(dev) for k, v in batch.items()}
+        model.compute_correspondences(data)
+        outs[heads] = data
+    tol = tol_for(golden, torch.float16, "182")
+    for k in KEYS:
+        d = rel(outs["split"][k], outs["fp32"][k])
+        e = rel(outs["split"][k], g[k])
+        print(k, "split vs fp32 heads %.2e   split vs reference %.2e (floor %.2e)" % (d, e, tol[k]))
+        assert d < 2e-5, (k, d)
+        assert e <= tol[k], (k, e, tol[k])
+
+
 _ORACLE_720 = {}
 
 
