@@ -69,7 +69,8 @@ class StageProfiler:
     # stage -> (governing bound, unit of work)
     STAGES = {
         "encoder_gemm": ("mfma", "flop"), "attention": ("mfma", "flop"), "conv_gemm": ("mfma", "flop"),
-        "head_gemm": ("hbm", "byte"), "layernorm": ("hbm", "byte"), "matcher": ("hbm", "byte"), "sampler": ("hbm", "byte"),
+        "head_gemm": ("hbm", "byte"), "split_planes": ("hbm", "byte"), "layernorm": ("hbm", "byte"), "matcher": ("hbm", "byte"),
+        "sampler": ("hbm", "byte"),
         "hypotheses_refine": (None, None),
     }
 
@@ -126,6 +127,12 @@ class StageProfiler:
         timed("conv3x3", "conv_gemm",
               lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, act=0, in2=None, C2=0, **k:
               2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
+        # split-operand convs (AMD.HEADS_DTYPE: split): the SAME algorithmic flops -- the three MFMA sweeps per product are the
+        # implementation's -- and the fp32 -> (hi, lo) plane conversions in front of them
+        timed("conv3x3_split", "conv_gemm",
+              lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, act=0, in2=None, C2=0, **k:
+              2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
+        timed("split_planes", "split_planes", lambda x, hi, lo, scale=64.0: 8.0 * x.numel())
         # the head linears (K = 128..256, fp32 qkv outputs) are write-bound: 1 flop per 3 bytes; priced against HBM
         timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:
               float(groups) * (M * K * esz(a) + N * K * esz(w) + M * N * esz(out)))
@@ -138,7 +145,7 @@ class StageProfiler:
         timed("layernorm", "layernorm", ln_bytes)
 
         def match_bytes(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None, want_scores=True, want_kp=True,
-                        want_final=True):
+                        want_final=True, split=False):
             B, C, n0 = dsc0.shape
             n1 = dsc1.shape[2]
             nout = int(want_scores) + int(want_kp and scr0 is not None) + int(want_final and scr0 is not None)
@@ -305,7 +312,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the vit_small and config5 legs")
-    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, vit_small, config5)")
+    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, ref_split_fp32mfma, vit_small, config5)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step sustained leg")
     ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no sustained / PCIe / "
                                                          "single-pair / CPU legs (profiling passes)")
@@ -648,8 +655,11 @@ def main(argv=None):
     if single and not args.no_alt and args.dtype == "bf16":
         leg("fp16", "fp16 operands everywhere: the reference's shipped low-precision mode for the encoder "
             "(MICKEY.DINOV2.FLOAT16), heads in fp16 too", "fp16", args.steps, args.warmup)
-        leg("ref_split", "fp16 encoder + fp32 heads (fp32 MFMA): the reference's exact precision split "
-            "(mickey_extractor.py:49-56)", "fp16", max(3, args.steps // 4), 1, heads="fp32")
+        leg("ref_split", "the reference's precision split (mickey_extractor.py:49-56): fp16 encoder + fp32 heads, the heads' 3x3 "
+            "convolutions on split fp16 operands (hi + lo planes, three MFMA sweeps: fp32-grade products; AMD.HEADS_DTYPE: split)",
+            "fp16", max(5, args.steps // 2), 2, heads="split")
+        leg("ref_split_fp32mfma", "the same split with the heads on the exact fp32-input MFMA (AMD.HEADS_DTYPE: fp32; round 3's "
+            "ref_split)", "fp16", 3, 1, heads="fp32")
         if "fp16" in out.get("legs", {}):
             out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
                           "note": "= legs.fp16 (kept for readers of the round-2 line)"}
