@@ -703,6 +703,21 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     auto plane_row = [&](void* plane, int half, int it) -> T* {   // uniform part: first row of the 4-row group
       return (T*)plane + (long long)(mw + half * 64 + it * 4) * p.ldxs;
     };
+    // Round 4: the planes are addressed as BUFFERS (SGPR descriptor + wave-uniform byte offset in an SGPR + the lane's constant
+    // 32-bit byte offset): a plane load / store is one instruction with no VALU address arithmetic (as 64-bit per-lane
+    // addresses each cost a v_lshl_add_u64: 6 of the ~70 VALU issues per 4 elements of this VALU-bound epilogue).  Byte
+    // offsets fit 32 bits: the launcher routes operands of 2^31 elements or more to the 128x128 kernel.
+    __amdgpu_buffer_rsrc_t rs_h, rs_l;
+    unsigned voff_b = 0;
+    if constexpr (SPLIT && EPI == MK_EPI_LS_RESIDUAL && sizeof(T) == 2) {
+      rs_h = __builtin_amdgcn_make_buffer_rsrc(p.xh, 0, 0x7fffffff, 0x00020000);
+      rs_l = __builtin_amdgcn_make_buffer_rsrc(p.xl, 0, 0x7fffffff, 0x00020000);
+      voff_b = lane_off * 2u;
+    }
+    auto soff_b = [&](int half, int it) -> unsigned {   // wave-uniform: byte offset of the first row of the 4-row group
+      return (unsigned)(mw + half * 64 + it * 4) * (unsigned)p.ldxs * 2u;
+    };
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     // it0 / it1: range of 4-row groups of the half (the split variant works in quarters, see the end of the function)
     auto preload = [&](int half, int it0 = 0, int it1 = 16) {
       if (EPI != MK_EPI_LS_RESIDUAL) return;
@@ -711,7 +726,12 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         if (it < it0 || it >= it1) continue;
         const int m = mw + half * 64 + it * 4 + rr;
         const bool ok = SPLIT || (m < p.M && n < p.N);
-        if (SPLIT) {
+        if constexpr (SPLIT && EPI == MK_EPI_LS_RESIDUAL && sizeof(T) == 2) {
+          const u32x2_t a = __builtin_amdgcn_raw_buffer_load_b64(rs_h, voff_b, soff_b(half, it), 0);
+          const u32x2_t b = __builtin_amdgcn_raw_buffer_load_b64(rs_l, voff_b, soff_b(half, it), 0);
+          xh[half][it] = uint2{a[0], a[1]};
+          xl[half][it] = uint2{b[0], b[1]};
+        } else if (SPLIT) {
           xh[half][it] = ok ? *(const uint2*)(plane_row(p.xh, half, it) + lane_off) : uint2{0u, 0u};
           xl[half][it] = ok ? *(const uint2*)(plane_row(p.xl, half, it) + lane_off) : uint2{0u, 0u};
         } else {
@@ -758,14 +778,19 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     // over this wave's 64 columns (one DPP row of 16 lanes holds one row segment); all lanes take part, invalid ones
     // contribute zeros.  fin: last block, fp32 rows out instead.
     constexpr bool fin = FIN;
-    auto emit_row = [&](long long xrow, T* dh, T* dl, f32x4 x, bool ok) {
+    auto emit_row = [&](long long xrow, T* dh, T* dl, f32x4 x, bool ok, unsigned soff = 0xffffffffu) {
       float ssum = 0.f, qsum = 0.f;
       if (ok) {
         const uint2 oh = pack4<T>(x);
         const uint2 ol = pack4<T>(x - unpack4<T>(oh));
         quad_stats(x, ssum, qsum);
-        *(uint2*)dh = oh;
-        *(uint2*)dl = ol;
+        if constexpr (SPLIT && EPI == MK_EPI_LS_RESIDUAL && sizeof(T) == 2) {
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{oh.x, oh.y}, rs_h, voff_b, soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ol.x, ol.y}, rs_l, voff_b, soff, 0);
+        } else {
+          *(uint2*)dh = oh;
+          *(uint2*)dl = ol;
+        }
       }
       ssum = row16_sum(ssum);
       qsum = row16_sum(qsum);
@@ -799,7 +824,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           if (!SPLIT || fin) {
             if (ok) *(f32x4*)(p.out_f32 + (long long)m * p.ldc + n) = x;
           } else {
-            emit_row(m, plane_row(p.xh, half, it) + lane_off_st, plane_row(p.xl, half, it) + lane_off_st, x, ok);
+            if constexpr (sizeof(T) == 2) emit_row(m, nullptr, nullptr, x, ok, soff_b(half, it));
+            else emit_row(m, plane_row(p.xh, half, it) + lane_off_st, plane_row(p.xl, half, it) + lane_off_st, x, ok);
           }
         } else if (EPI == MK_EPI_PATCH) {
           const int mc = ok ? m : 0;
