@@ -51,6 +51,7 @@ SIGNATURES = {
     "mk_dual_softmax_split": ("i", "ppppfifppppiiiip"),
     "mk_sinkhorn_work_floats": ("l", "iii"),
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
+    "mk_sinkhorn_set_group": ("i", "i"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iii"),
     "mk_exprace_topk": ("i", "ppuupppppiiliip"),

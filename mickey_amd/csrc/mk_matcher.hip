@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void couplings_kernel(const float* __restrict_
 }
 
 // u2[i] = log_mu2[i] - LSE2_j(Z2[i][j] + v2[j]); one wave per row, 16 bytes per lane
+template <bool NT>
 __global__ __launch_bounds__(256) void sink_row_kernel(const float* __restrict__ Z, const float* __restrict__ v,
                                                        float* __restrict__ u, int n0, int ldz, int ldu, float norm2, float last2) {
   const int lane = threadIdx.x & 63;
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void sink_row_kernel(const float* __restrict__
   const f32x4* vb = (const f32x4*)(v + (long long)b * ldz);
   float m = -1e30f, s = 0.f;
   for (int j4 = lane; j4 < (ldz >> 2); j4 += 64) {
-    const f32x4 x = __builtin_nontemporal_load(z + j4) + vb[j4];
+    const f32x4 x = (NT ? __builtin_nontemporal_load(z + j4) : z[j4]) + vb[j4];
     const float M = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), m);
     s = s * __builtin_amdgcn_exp2f(m - M) + ((__builtin_amdgcn_exp2f(x[0] - M) + __builtin_amdgcn_exp2f(x[1] - M)) +
                                              (__builtin_amdgcn_exp2f(x[2] - M) + __builtin_amdgcn_exp2f(x[3] - M)));
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(256) void sink_row_kernel(const float* __restrict__
 
 // column pass, part 1: (max, sum) of 2^(Z2[i][j] + u2[i]) over the rows of one 256-row chunk for 256 columns; a wave takes 64 of
 // the rows, 8 at a time (one running-maximum update per 8 values of a column), a lane 4 adjacent columns
+template <bool NT>
 __global__ __launch_bounds__(256) void sink_col_part_kernel(const float* __restrict__ Z, const float* __restrict__ u,
                                                             float2* __restrict__ part, int n0, int ldz, int ldu, int nrc) {
   __shared__ f32x4 sm[4][64], ss[4][64];
@@ -522,7 +524,8 @@ __global__ __launch_bounds__(256) void sink_col_part_kernel(const float* __restr
       // rows past the end repeat the last row with -inf added: no branch in the loads
       const int ic = i <= n0 ? i : n0;
       const float ui = i <= n0 ? ub[ic] : -1e30f;
-      x[k] = __builtin_nontemporal_load((const f32x4*)(Zb + (long long)ic * ldz)) + ui;
+      const f32x4* zp = (const f32x4*)(Zb + (long long)ic * ldz);
+      x[k] = (NT ? __builtin_nontemporal_load(zp) : *zp) + ui;
     }
     f32x4 M = m;
 #pragma unroll
@@ -701,6 +704,8 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 
 }  // namespace
 
+static int g_sk_group = 0;   // Sinkhorn: pairs iterated together (0 automatic, < 0 the whole batch with non-temporal reads)
+
 extern "C" {
 
 long long mk_dual_softmax_work_floats(int B, int n0, int n1, int own_copy) {
@@ -822,21 +827,51 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const f
   const float LOG2E = 1.4426950408889634f;
   const float norm = -logf((float)n0 + (float)n1);
   const float norm2 = norm * LOG2E, mu_last2 = (logf((float)n1) + norm) * LOG2E, nu_last2 = (logf((float)n0) + norm) * LOG2E;
-  hipLaunchKernelGGL(couplings_kernel, dim3((ldz + MT - 1) / MT, (n0 + 1 + MT - 1) / MT, B), dim3(256), 0, st, dsc0, dsc1,
-                     LOG2E / sqrtf((float)C), alpha * LOG2E, Z, C, n0, n1, ldz);
-  MK_CHECK_LAUNCH();
-  const long long nuv = (long long)B * (ldu + ldz);
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((nuv + 255) / 256)), dim3(256), 0, st, u, 0.f, nuv);
-  MK_CHECK_LAUNCH();
-  for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(sink_row_kernel, dim3((n0 + 1 + 3) / 4, B), dim3(256), 0, st, Z, v, u, n0, ldz, ldu, norm2, mu_last2);
-    hipLaunchKernelGGL(sink_col_part_kernel, dim3((ldz / 4 + 63) / 64, nrc, B), dim3(256), 0, st, Z, u, part, n0, ldz, ldu, nrc);
-    hipLaunchKernelGGL(sink_col_fin_kernel, dim3((ldz + 255) / 256, B), dim3(256), 0, st, part, v, n1, ldz, nrc, norm2, nu_last2);
+  // The 20 LSE passes of a pair re-read its (n0+1) x ldz coupling matrix (15 MB at 540x720, 86 MB at 1280x720).  Iterating
+  // batch-wide (round 3) streams B matrices through the 256-MB Infinity Cache between two reads of the same one; here the
+  // batch is cut into groups of pairs whose matrices fit it together, and a group runs ALL its iterations before the next
+  // starts (reads without the non-temporal hint, so that the lines stay).  g_sk_group: dev knob (mk_sinkhorn_set_group).
+  const long long zbytes = (long long)(n0 + 1) * ldz * 4;
+  int group = g_sk_group > 0 ? g_sk_group : (int)(((200LL << 20)) / zbytes);   // automatic: what fits ~200 MB
+  if (group < 1) group = 1;
+  if (group > B || g_sk_group < 0) group = B;                                   // < 0: batch-wide, non-temporal (the round-3 order)
+  const bool nt = g_sk_group < 0 || (long long)group * zbytes > (240LL << 20);
+  for (int b0 = 0; b0 < B; b0 += group) {
+    const int nb = group < B - b0 ? group : B - b0;
+    const float* d0 = dsc0 + (long long)b0 * C * n0;
+    const float* d1 = dsc1 + (long long)b0 * C * n1;
+    float* Zg = Z + (long long)b0 * (n0 + 1) * ldz;
+    float* ug = u + (long long)b0 * ldu;
+    float* vg = v + (long long)b0 * ldz;
+    float2* pg = part + (long long)b0 * nrc * ldz;
+    hipLaunchKernelGGL(couplings_kernel, dim3((ldz + MT - 1) / MT, (n0 + 1 + MT - 1) / MT, nb), dim3(256), 0, st, d0, d1,
+                       LOG2E / sqrtf((float)C), alpha * LOG2E, Zg, C, n0, n1, ldz);
+    MK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)nb * ldu + 255) / 256)), dim3(256), 0, st, ug, 0.f, (long long)nb * ldu);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)nb * ldz + 255) / 256)), dim3(256), 0, st, vg, 0.f, (long long)nb * ldz);
+    MK_CHECK_LAUNCH();
+    for (int it = 0; it < iters; ++it) {
+      if (nt) {
+        hipLaunchKernelGGL(sink_row_kernel<true>, dim3((n0 + 1 + 3) / 4, nb), dim3(256), 0, st, Zg, vg, ug, n0, ldz, ldu, norm2, mu_last2);
+        hipLaunchKernelGGL(sink_col_part_kernel<true>, dim3((ldz / 4 + 63) / 64, nrc, nb), dim3(256), 0, st, Zg, ug, pg, n0, ldz, ldu, nrc);
+      } else {
+        hipLaunchKernelGGL(sink_row_kernel<false>, dim3((n0 + 1 + 3) / 4, nb), dim3(256), 0, st, Zg, vg, ug, n0, ldz, ldu, norm2, mu_last2);
+        hipLaunchKernelGGL(sink_col_part_kernel<false>, dim3((ldz / 4 + 63) / 64, nrc, nb), dim3(256), 0, st, Zg, ug, pg, n0, ldz, ldu, nrc);
+      }
+      hipLaunchKernelGGL(sink_col_fin_kernel, dim3((ldz + 255) / 256, nb), dim3(256), 0, st, pg, vg, n1, ldz, nrc, norm2, nu_last2);
+    }
+    MK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, nb), dim3(256), 0, st, Zg, ug, vg, norm2,
+                       scr0 ? scr0 + (long long)b0 * n0 : nullptr, scr1 ? scr1 + (long long)b0 * n1 : nullptr,
+                       scores ? scores + (long long)b0 * n0 * n1 : nullptr, kp_scores ? kp_scores + (long long)b0 * n0 * n1 : nullptr,
+                       final_scores ? final_scores + (long long)b0 * n0 * n1 : nullptr, n0, n1, ldz, ldu);
+    MK_CHECK_LAUNCH();
   }
-  MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sink_final_kernel, dim3((n1 + 255) / 256, n0, B), dim3(256), 0, st, Z, u, v, norm2, scr0, scr1, scores, kp_scores,
-                     final_scores, n0, n1, ldz, ldu);
-  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_sinkhorn_set_group(int pairs) {
+  g_sk_group = pairs;
   return MK_OK;
 }
 

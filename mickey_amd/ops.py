@@ -283,6 +283,11 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
     return scores, kp, fin
 
 
+def sinkhorn_set_group(pairs):
+    """Dev knob (mickey_hip_dev.h): pairs iterated together by mk_sinkhorn (0 automatic, < 0 batch-wide / non-temporal)."""
+    call("mk_sinkhorn_set_group", int(pairs))
+
+
 def sinkhorn(dsc0, dsc1, alpha, iters=10, scr0=None, scr1=None, want_scores=True, want_kp=False, want_final=False):
     """Returns scores, or (scores, kp_scores, final_scores) when scr0/scr1 are given."""
     B, C, n0 = dsc0.shape
