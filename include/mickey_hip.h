@@ -184,12 +184,14 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
  *   in1_hi / in1_lo, in2_hi / in2_lo: bordered fp16 feature maps (mk_split_planes of the fp32 maps, scale s_a);
  *   W: fp16 [Cout, 3 K], K = 9 C1 + C2, = [W_hi | W_lo | W_hi] of the BatchNorm-folded weights times s_w (the HI weights meet
  *      the LO activations in sweep 0); an identity shortcut is passed as in2 = the block input with identity columns in W;
- *   out: fp32 [.., Cout], dense rows or (out_bordered) a bordered feature map; acc_scale = 1 / (s_a s_w), applied to the
- *      accumulators before bias / activation. */
+ *   out: out_lo == NULL: fp32 [.., Cout], dense rows or (out_bordered) a bordered feature map; out_lo != NULL: the result
+ *      goes out as the NEXT split conv's operand planes instead, fp16 out = hi, out_lo = lo of result * plane_scale (same
+ *      layout; saturating at fp16's largest finite value); acc_scale = 1 / (s_a s_w), applied to the accumulators before
+ *      bias / activation. */
 int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
                      long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
-                     long long strideBias, float* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd,
-                     int act, int out_bordered, float acc_scale, mk_stream_t stream);
+                     long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
+                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, mk_stream_t stream);
 
 /* fp32 [n] -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504).  n % 4 == 0. */
 int mk_split_planes(const float* src, long long n, float scale, void* hi, void* lo, mk_stream_t stream);

@@ -24,9 +24,9 @@ int mk_gemm_set_tile(int mode);
  * kernel (64 queries per wave; A/B partner).  Process-wide; for benchmarks and tests. */
 int mk_attn_set_mode(int mode);
 
-/* mk_sinkhorn: image pairs iterated together through all Sinkhorn iterations (their coupling matrices are meant to stay in
- * the 256-MB Infinity Cache between the 20 passes): 0 = automatic (as many as fit ~200 MB), n > 0 = n pairs, < 0 = the whole
- * batch per pass with non-temporal reads (round 3's order; A/B partner). */
+/* mk_sinkhorn: n > 0 = n image pairs iterated together through all Sinkhorn iterations (so that their coupling matrices could
+ * stay in the 256-MB Infinity Cache between the 20 passes; measured no faster: profiles/r04c_bench_matcher.txt), 0 = the
+ * whole batch per pass with non-temporal reads (default). */
 int mk_sinkhorn_set_group(int pairs);
 
 #ifdef __cplusplus

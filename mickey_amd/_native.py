@@ -38,7 +38,7 @@ SIGNATURES = {
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_bordered_rows": ("l", "iii"),
     "mk_conv3x3": ("i", "pliplipilplplpiliiiiiiip"),
-    "mk_conv3x3_split": ("i", "pplipplipilplpiliiiiiifp"),
+    "mk_conv3x3_split": ("i", "pplipplipilplppiliiiiiiffp"),
     "mk_split_planes": ("i", "plfppp"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
     "mk_linattn_work_floats": ("l", "iiii"),
@@ -51,7 +51,6 @@ SIGNATURES = {
     "mk_dual_softmax_split": ("i", "ppppfifppppiiiip"),
     "mk_sinkhorn_work_floats": ("l", "iii"),
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
-    "mk_sinkhorn_set_group": ("i", "i"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iii"),
     "mk_exprace_topk": ("i", "ppuupppppiiliip"),
@@ -71,6 +70,7 @@ SIGNATURES = {
 DEV_SIGNATURES = {
     "mk_gemm_set_tile": ("i", "i"),
     "mk_attn_set_mode": ("i", "i"),
+    "mk_sinkhorn_set_group": ("i", "i"),
 }
 
 _lib = None

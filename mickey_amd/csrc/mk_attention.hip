@@ -7,7 +7,7 @@
 //  * two kernels share this design (mk_attn_set_mode): attn_fwd_fold_kernel (production: the lean softmax -- running maximum
 //    folded into the accumulator init, re-based only when a tile outgrows it, detected from the row sums -- with fp32 row sums on the VALU) and
 //    attn_fwd_kernel (classic online softmax, kept as the A/B partner).  Round 3 built and measured three more structures
-//    (one wave per SIMD with an asm-owned accumulator file, ping-pong wave-rows, matrix-pipe row sums): DESIGN.md 2.2.
+//    (one wave per SIMD with an asm-owned accumulator file, ping-pong wave-rows, matrix-pipe row sums): LABNOTES.md 2.2.
 //  * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] go HBM -> LDS with global_load_lds
 //    (lane-linear image; XOR swizzle on the source address + on the ds_read_b128), double-buffered.
 //  * S^T = K.Q^T ("swapped" product): after the MFMA a lane holds 32 scores of ONE query, so the

@@ -375,8 +375,8 @@ int mk_split_planes(const float* src, long long n, float scale, void* hi, void* 
 
 int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
                      long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
-                     long long strideBias, float* out, int Cout, long long strideOut, int groups, int nimg, int H, int Wd,
-                     int act, int out_bordered, float acc_scale, mk_stream_t stream) {
+                     long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
+                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, mk_stream_t stream) {
   GemmParams p = {};
   p.A = in1_hi; p.A_lo = in1_lo; p.A2 = in2_hi; p.A2_lo = in2_lo; p.W = W;
   p.npass = 3; p.acc_scale = acc_scale;
@@ -385,7 +385,8 @@ int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in
   p.strideBias_g = strideBias; p.strideOut_g = strideOut;
   p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2_hi ? C2 : 0;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout;
-  p.out_f32 = out; p.bord_out = out_bordered ? 1 : 0;
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; } else { p.out_f32 = (float*)out; }
+  p.bord_out = out_bordered ? 1 : 0;
   if (int e = check_common(p, MK_F16)) return e;
   MK_CHECK_ARG(in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");
   MK_CHECK_ARG(C1 % BK == 0 && (!in2_hi || C2 % BK == 0), "mk_conv3x3_split: channel counts must be multiples of the K tile (%d)", BK);

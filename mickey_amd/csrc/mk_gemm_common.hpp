@@ -31,6 +31,10 @@ struct GemmParams {
   const void* A2_lo;
   int npass;           // 0 / 1: plain; 3: split operands
   float acc_scale;
+  // ... whose output feeds another split conv: written straight as the next conv's operand planes, out_lp = hi, out_lo = lo
+  // (fp16, v * plane_scale = hi + lo) instead of fp32 rows + a separate mk_split_planes pass
+  void* out_lo;
+  float plane_scale;
   // epilogue
   int epi;
   int act;
@@ -462,7 +466,19 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
         } else if (ACT == MK_ACT_GELU) {
           v = gelu_erf4(v);
         }
-        if (p.out_f32) {
+        if (p.out_lo) {   // split-operand conv chain: the next conv's (hi, lo) planes
+          const float ps = p.plane_scale;
+          f16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sv = fminf(v[e] * ps, 65504.f);   // (post-ReLU or small: only the upper end can overflow fp16)
+            oh[e] = (_Float16)sv;
+            ol[e] = (_Float16)(sv - (float)oh[e]);
+          }
+          const long long o = (long long)g * p.strideOut_g + (p.bord_out ? brow : (long long)m) * p.ldc + n;
+          *(f16x4*)((_Float16*)p.out_lp + o) = oh;
+          *(f16x4*)((_Float16*)p.out_lo + o) = ol;
+        } else if (p.out_f32) {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + (p.bord_out ? brow : (long long)m) * p.ldc + n) = v;
         } else {
           V4 o;
@@ -542,7 +558,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
 // only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
 // XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
-// SPLIT (split residual stream, §2.1b of DESIGN.md) is instantiated for INTERIOR tiles only (no row / column predicates:
+// SPLIT (split residual stream, §2.1b of LABNOTES.md) is instantiated for INTERIOR tiles only (no row / column predicates:
 // straight-line code; with per-row branches this variant pushed the whole kernel over 256 VGPRs and hipcc spilled half the
 // accumulators of every tile of every launch) -- edge tiles take the direct epilogue; FIN: fp32 rows out (last block).
 template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false, bool FIN = false, bool CONV = false>
@@ -584,7 +600,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
   float2 prm[8];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) prm[mi] = LN ? lnp[wm * 128 + mi * 16 + fr] : make_float2(1.f, 0.f);
-  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32);
+  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32 && !(CONV && p.out_lo));
   if (lp_out) {
     int which = 0, head = 0;
     if (EPI == MK_EPI_QKV) {
@@ -835,6 +851,18 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           if (ok) x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
           if (SPLIT) emit_row(xrow, (T*)p.xh + xrow * p.ldxs + n, (T*)p.xl + xrow * p.ldxs + n, x, ok);
           else if (ok) *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
+        } else if (CONV && p.out_lo) {   // split-operand conv chain: the next conv's (hi, lo) planes, 8 bytes per lane each
+          const float ps = p.plane_scale;
+          f16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sv = fminf(val[e] * ps, 65504.f);
+            oh[e] = (_Float16)sv;
+            ol[e] = (_Float16)(sv - (float)oh[e]);
+          }
+          const long long o = (long long)g * p.strideOut_g + ((long long)m + extraf) * p.ldc + n;
+          *(f16x4*)((_Float16*)p.out_lp + o) = oh;
+          *(f16x4*)((_Float16*)p.out_lo + o) = ol;
         } else {
           *(f32x4*)(p.out_f32 + (long long)g * p.strideOut_g + ((long long)m + extraf) * p.ldc + n) = val;
         }

@@ -11,6 +11,8 @@
 //   merge   partials (+ dustbin term) -> log2-sum-exp vectors of both directions;
 //   pass 2  element-wise: scores = 2^((v - lse_col) + (v - lse_row)), kp_scores = scr0 (x) scr1,
 //           final_scores = scores * kp_scores (each optional), in place over the stored correlation where possible.
+#include <type_traits>
+
 #include "mk_common.hpp"
 
 namespace {
@@ -398,17 +400,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-// pass 2: the same correlation, outputs from registers.  scores = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores kp
+// pass 2: the same correlation, outputs from registers -- through LDS.  In the accumulator layout a lane owns ONE column of
+// the tile: stored from there an instruction writes 4 bytes per lane, 128 contiguous bytes per output row (round 4's first
+// version: 1.9 TB/s, 0.75 ms for the three 480-MB outputs of 32 pairs -- the vector memory path, not HBM, was the limit).
+// Here a wave computes TWO column tiles (32 rows x 64 columns), transposes each output through an 8-KiB private LDS slice
+// (wave-local, LDS is in-order per wave: no barrier) and writes 16 bytes per lane, 256 contiguous bytes per row.
+// scores = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores kp.
+template <int VEC>   // floats per lane of an output store: 4 when the output rows are 16-byte aligned (n1 % 4 == 0), 2 for even n1
+                     // (n1 = 1938, the Map-free grid), else 1
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_split_apply_kernel(
     const uint4* __restrict__ P0, const uint4* __restrict__ P1, float scale2, const float* __restrict__ scr0,
     const float* __restrict__ scr1, const float* __restrict__ lse2, float* __restrict__ scores, float* __restrict__ kp,
     float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits) {
+  __shared__ __attribute__((aligned(16))) float stage[4][RT * 64];
   int bx, by, b;
   if (!decode_unit_grid(gx, NCHUNK_S, nunits, bx, by, b)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rb = bx * 4 + wave, i0 = rb * RT;
   if (rb >= nrb) return;
+  float* st = stage[wave];
   SplitOperand a, bq;
   a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
   const int per = (ntb + NCHUNK_S - 1) / NCHUNK_S;
@@ -422,24 +433,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     s0[r] = scr0 ? scr0[(long long)b * n0 + ic] : 0.f;
   }
   const uint4* pb = P1 + (long long)b * ntb * SP_BLK_U4;
-  for (int jt = jt0; jt < jt1; ++jt) {
-    bq.load(pb + (long long)jt * SP_BLK_U4, lane);
-    const f32x16 acc = corr_split(a, bq);
-    const int j = jt * RT + l31;
-    if (j >= n1) continue;
-    const float lc = lse2[((long long)b * 2 + 1) * nmax + j];
-    const float s1 = scr1 ? scr1[(long long)b * n1 + j] : 0.f;
+  typedef float VT __attribute__((ext_vector_type(VEC)));
+  constexpr int LPR = 64 / VEC, RPI = 64 / LPR;   // lanes per 64-column row, rows per store instruction
+  const int dr = lane / LPR, dc = (lane % LPR) * VEC;
+  for (int jt = jt0; jt < jt1; jt += 2) {
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (i >= n0) continue;
-      const float v = acc[r] * scale2;
-      const float p = __builtin_amdgcn_exp2f((v - lc) + (v - lr[r]));
-      const float k = s0[r] * s1;
-      const long long o = ((long long)b * n0 + i) * n1 + j;
-      if (scores) scores[o] = p;
-      if (kp) kp[o] = k;
-      if (fin) fin[o] = p * k;
+    for (int t = 0; t < 2; ++t) {
+      bq.load(pb + (long long)min(jt + t, ntb - 1) * SP_BLK_U4, lane);
+      acc[t] = corr_split(a, bq);
+    }
+    float lc[2], s1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = (jt + t) * RT + l31;
+      const int jc = j < n1 ? j : n1 - 1;
+      lc[t] = lse2[((long long)b * 2 + 1) * nmax + jc];
+      s1[t] = scr1 ? scr1[(long long)b * n1 + jc] : 0.f;
+    }
+    const int jbase = jt * RT;   // first column of the pair of tiles; columns of tile jt + 1 past jt1 / n1 are never stored
+    const int jlim = min(n1, min(jt + 2, jt1) * RT);
+#pragma unroll 1
+    for (int which = 0; which < 3; ++which) {   // 0 scores, 1 kp_scores, 2 final_scores: one LDS round trip each
+      float* out = which == 0 ? scores : which == 1 ? kp : fin;
+      if (!out) continue;   // wave-uniform
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * scale2;
+          const float pv = __builtin_amdgcn_exp2f((v - lc[t]) + (v - lr[r]));
+          const float kv = s0[r] * s1[t];
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          st[row * 64 + t * 32 + l31] = which == 0 ? pv : which == 1 ? kv : pv * kv;
+        }
+#pragma unroll 8   // (VEC = 1 has 32 iterations: all of them in flight at once spill)
+      for (int it = 0; it < RT / RPI; ++it) {
+        const int row = dr + RPI * it, i = i0 + row, j = jbase + dc;
+        const VT val = *(const VT*)(st + row * 64 + dc);
+        if (i < n0 && j + VEC <= jlim) *(VT*)(out + ((long long)b * n0 + i) * n1 + j) = val;   // (jlim is a multiple of VEC)
+      }
     }
   }
 }
@@ -704,7 +737,7 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 
 }  // namespace
 
-static int g_sk_group = 0;   // Sinkhorn: pairs iterated together (0 automatic, < 0 the whole batch with non-temporal reads)
+static int g_sk_group = 0;   // Sinkhorn: pairs iterated together (0: the whole batch per pass with non-temporal reads)
 
 extern "C" {
 
@@ -794,8 +827,16 @@ int mk_dual_softmax_split(const float* dsc0, const float* dsc1, const float* scr
                      dustbin * LOG2E, n0, n1, nmax, nrb, NCHUNK_S);
   MK_CHECK_LAUNCH();
   if (scores || kp_scores || final_scores) {
-    hipLaunchKernelGGL(dual_softmax_split_apply_kernel, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
-                       final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+    const bool a16 = ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 15) == 0);
+    if ((n1 & 3) == 0 && a16)
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<4>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+    else if ((n1 & 1) == 0 && ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 7) == 0))
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<2>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+    else
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<1>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
     MK_CHECK_LAUNCH();
   }
   return MK_OK;
@@ -827,15 +868,16 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const f
   const float LOG2E = 1.4426950408889634f;
   const float norm = -logf((float)n0 + (float)n1);
   const float norm2 = norm * LOG2E, mu_last2 = (logf((float)n1) + norm) * LOG2E, nu_last2 = (logf((float)n0) + norm) * LOG2E;
-  // The 20 LSE passes of a pair re-read its (n0+1) x ldz coupling matrix (15 MB at 540x720, 86 MB at 1280x720).  Iterating
-  // batch-wide (round 3) streams B matrices through the 256-MB Infinity Cache between two reads of the same one; here the
-  // batch is cut into groups of pairs whose matrices fit it together, and a group runs ALL its iterations before the next
-  // starts (reads without the non-temporal hint, so that the lines stay).  g_sk_group: dev knob (mk_sinkhorn_set_group).
+  // The 20 LSE passes of a pair re-read its (n0+1) x ldz coupling matrix (15 MB at 540x720, 86 MB at 1280x720).  Round 4
+  // measured whether cutting the batch into groups of pairs whose matrices fit the 256-MB Infinity Cache together -- a group
+  // runs ALL its iterations before the next starts, reads without the non-temporal hint -- turns HBM passes into cache hits:
+  // it does not (8 pairs of 1280x720: 5.49 ms batch-wide, 5.64 / 5.64 / 6.09 ms in groups of 4 / 2 / 1,
+  // profiles/r04c_bench_matcher.txt).  The batch-wide order stays the default; g_sk_group > 0 (dev knob
+  // mk_sinkhorn_set_group) selects the grouped one.
   const long long zbytes = (long long)(n0 + 1) * ldz * 4;
-  int group = g_sk_group > 0 ? g_sk_group : (int)(((200LL << 20)) / zbytes);   // automatic: what fits ~200 MB
-  if (group < 1) group = 1;
-  if (group > B || g_sk_group < 0) group = B;                                   // < 0: batch-wide, non-temporal (the round-3 order)
-  const bool nt = g_sk_group < 0 || (long long)group * zbytes > (240LL << 20);
+  int group = g_sk_group > 0 ? g_sk_group : B;
+  if (group > B) group = B;
+  const bool nt = g_sk_group <= 0 || (long long)group * zbytes > (240LL << 20);
   for (int b0 = 0; b0 < B; b0 += group) {
     const int nb = group < B - b0 ? group : B - b0;
     const float* d0 = dsc0 + (long long)b0 * C * n0;

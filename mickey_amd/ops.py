@@ -212,13 +212,20 @@ def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
 
 def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, stride_in1=0, stride_in2=0,
                   stride_w=0, stride_bias=0, stride_out=0, out_bordered=False):
-    """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes, w fp16 [.., Cout, 3 K], out fp32."""
-    assert out.dtype == torch.float32 and w.dtype == torch.float16
+    """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes, w fp16 [.., Cout, 3 K]; out: an fp32 tensor, or
+    a (hi, lo) pair of fp16 planes = the operand form of the next split conv (no fp32 round trip, no mk_split_planes pass)."""
+    assert w.dtype == torch.float16
     h1, l1 = in1
     h2, l2 = in2 if in2 is not None else (None, None)
+    if isinstance(out, (tuple, list)):
+        oh, ol = out
+        assert oh.dtype == torch.float16 and ol.dtype == torch.float16 and oh.shape == ol.shape
+    else:
+        oh, ol = out, None
+        assert out.dtype == torch.float32
     call("mk_conv3x3_split", ptr(h1), ptr(l1), stride_in1, C1, ptr(h2), ptr(l2), stride_in2, C2, ptr(w), w.shape[-1], stride_w,
-         ptr(bias), stride_bias, ptr(out), Cout, stride_out, groups, nimg, H, W, act, int(out_bordered),
-         1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), stream())
+         ptr(bias), stride_bias, ptr(oh), ptr(ol), Cout, stride_out, groups, nimg, H, W, act, int(out_bordered),
+         1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), SPLIT_ACT_SCALE, stream())
     return out
 
 
@@ -284,7 +291,7 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
 
 
 def sinkhorn_set_group(pairs):
-    """Dev knob (mickey_hip_dev.h): pairs iterated together by mk_sinkhorn (0 automatic, < 0 batch-wide / non-temporal)."""
+    """Dev knob (mickey_hip_dev.h): pairs iterated together by mk_sinkhorn (0 = batch-wide, non-temporal reads: default)."""
     call("mk_sinkhorn_set_group", int(pairs))
 
 

@@ -117,23 +117,30 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
         lo = ws.get(name + "_lo" + geo, tuple(x.shape), torch.float16, dev)
         return ops.split_planes(x, hi, lo)
 
+    def plane_pair(name, shape):
+        """Zeroed (hi, lo) fp16 planes of a bordered activation that a split conv WRITES (the next split conv's operands)."""
+        return (ws.get(name + "_hi" + geo, shape, torch.float16, dev, zero=True), ws.get(name + "_lo" + geo, shape, torch.float16, dev, zero=True))
+
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
     xp = planes("feat", feat) if split else None
     for bi, rb in enumerate(W.rb):
         co = rb.cout
         last = bi == len(W.rb) - 1   # its output feeds the attention layers (row-wise kernels): dense rows
-        h1 = ws.get("rb%d_h" % bi + geo, (G, R, co), lp, dev, zero=True)
-        xo = ws.get("rb%d_x" % bi + geo, (G, M if last else R, co), lp, dev, zero=not last)
         if split:
-            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
+            # conv -> conv inside the stack: the epilogue writes the next conv's (hi, lo) operand planes directly (no fp32
+            # round trip, no mk_split_planes pass); only the stack's output (read by the row-wise attention kernels) is fp32
+            hp = plane_pair("rb%d_h" % bi, (G, R, co))
+            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
                               stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
-            hp = planes("rb%d_h" % bi, h1)
+            xo = ws.get("rb%d_x" % bi + geo, (G, M, co), lp, dev) if last else plane_pair("rb%d_x" % bi, (G, R, co))
             ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in,
                               stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
                               stride_out=(M if last else R) * co, out_bordered=not last)
             if not last:
-                xp = planes("rb%d_x" % bi, xo)
+                xp = xo
         else:
+            h1 = ws.get("rb%d_h" % bi + geo, (G, R, co), lp, dev, zero=True)
+            xo = ws.get("rb%d_x" % bi + geo, (G, M if last else R, co), lp, dev, zero=not last)
             ops.conv3x3(x_in, c_in, rb.w1, rb.b1, h1, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
                         stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
             ops.conv3x3(h1, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=x_in, C2=c_in,
@@ -175,23 +182,25 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout
-    h4 = ws.get("rb4_h" + geo, (3, R, ck), lp, dev, zero=True)
     f4 = ws.get("rb4_f", (3, M, ck), torch.float32, dev)
     cd = dw.cout
-    hd = ws.get("rb4_hd" + geo, (R, cd), lp, dev, zero=True)
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
     if split:
         x4h, x4l = planes("att_out", x4)
-        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
+        h4p = plane_pair("rb4_h", (3, R, ck))
+        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
                           stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
         assert kpw.has_sc and dw.has_sc   # (weights.prepare gives the descriptor block identity shortcut columns in this mode)
-        ops.conv3x3_split(planes("rb4_h", h4), ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
+        ops.conv3x3_split(h4p, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
                           in2=(x4h[:3], x4l[:3]), C2=C, stride_in1=R * ck, stride_in2=R * C,
                           stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
-        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hd, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
-        ops.conv3x3_split(planes("rb4_hd", hd), cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,
+        hdp = plane_pair("rb4_hd", (R, cd))
+        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hdp, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
+        ops.conv3x3_split(hdp, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,
                           in2=(x4h[3], x4l[3]), C2=C)   # relu=False, mickey_extractor.py:246
     else:
+        h4 = ws.get("rb4_h" + geo, (3, R, ck), lp, dev, zero=True)
+        hd = ws.get("rb4_hd" + geo, (R, cd), lp, dev, zero=True)
         ops.conv3x3(x4, C, kpw.w1, kpw.b1, h4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
                     stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
         ops.conv3x3(h4, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,

@@ -147,7 +147,7 @@ def test_intrinsics_rescale_matches_the_reference_formula():
 def test_no_product_kernel_spills_registers():
     """Per-kernel register report of the build (hipcc -Rpass-analysis=kernel-resource-usage -> build/resource_usage.json).
     All epilogues of a GEMM kernel share ONE register allocation: a variant over 256 VGPRs makes hipcc spill the
-    accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward).
+    accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward, LABNOTES.md section 6).
     No kernel of the library is exempt.  The report is written by build(); a checkout whose objects were built elsewhere
     (no json) skips."""
     import glob
@@ -246,7 +246,8 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
                 pass
             fake = _Ops()
             for nm in ("gemm", "gemm_ls_residual", "gemm_qkv", "gemm_patch_embed", "gemm_ln", "gemm_qkv_ln", "gemm_ls_residual_ln",
-                       "gemm_patch_embed_ln", "flash_attn", "conv3x3", "gemm_grouped", "layernorm", "dual_softmax", "sinkhorn",
+                       "gemm_patch_embed_ln", "flash_attn", "conv3x3", "conv3x3_split", "split_planes", "gemm_grouped", "layernorm",
+                       "dual_softmax", "sinkhorn",
                        "exprace_topk", "gather_backproject", "ransac_hypotheses", "refine_pose"):
                 setattr(fake, nm, lambda *a, **k: None)
             ev = type("E", (), {"record": lambda self: None, "elapsed_time": lambda self, o: 1.0})

@@ -606,6 +606,19 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
         worst = max(worst, e_split)
         assert e_split < 2e-6 and e_split < 4 * e_f32 + 2e-7, (gi, e_split, e_f32)
     print("split conv vs fp64: %.2e" % worst)
+    # the same conv writing the NEXT split conv's operand planes instead of fp32 rows: (hi + lo) / scale == the fp32 result to
+    # the planes' 22 bits, border rows untouched
+    rows = R if bordered else M
+    ph = torch.full((G, rows, Cout), 7.0, device=dev, dtype=torch.float16)
+    pl = torch.full((G, rows, Cout), 7.0, device=dev, dtype=torch.float16)
+    ops.conv3x3_split((xh, xl), C1, wsplit, bias, (ph, pl), Cout, G, nimg, H, W, act=ops.ACT_RELU, in2=in2, C2=C2,
+                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 3 * K, stride_bias=Cout, stride_out=rows * Cout,
+                      out_bordered=bordered)
+    if bordered:
+        assert bool((ph[:, mask] == 7.0).all()) and bool((pl[:, mask] == 7.0).all())
+        ph, pl = ph[:, idx], pl[:, idx]
+    back = (ph.double() + pl.double()) / ops.SPLIT_ACT_SCALE
+    assert float((back - out.double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
 
 
 def test_grouped_gemm():
