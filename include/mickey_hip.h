@@ -193,8 +193,19 @@ int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in
                      long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
                      int Wd, int act, int out_bordered, float acc_scale, float plane_scale, mk_stream_t stream);
 
-/* fp32 [n] -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504).  n % 4 == 0. */
-int mk_split_planes(const float* src, long long n, float scale, void* hi, void* lo, mk_stream_t stream);
+/* fp32 [rows, cols] (row stride ld_src) -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504),
+ * each [rows, cols] with row stride ld_dst.  cols, ld_src, ld_dst % 4 == 0. */
+int mk_split_planes(const float* src, long long rows, int cols, long long ld_src, float scale, void* hi, void* lo,
+                    long long ld_dst, mk_stream_t stream);
+
+/* Grouped GEMM with SPLIT operands (the small linears of the heads' attention layers in AMD.HEADS_DTYPE: split; reference
+ * att_layers/transformer_utils.py:51-66 runs them in fp32): out[g] = act(A[g] W[g]^T + bias[g]) with A = (A_hi + A_lo) / s_a
+ * as fp16 planes [M, lda] and W fp16 [N, 3 K] = [W_hi | W_lo | W_hi] of the weights times s_w -- lo.hi + hi.lo + hi.hi on the
+ * 16-bit matrix cores, fp32 accumulation (as mk_conv3x3_split).  out: fp32 [M, ldc], or with out_lo != NULL the (hi, lo)
+ * planes of result * plane_scale.  K % 64 == 0. */
+int mk_gemm_grouped_split(const void* A_hi, const void* A_lo, int lda, long long strideA, const void* W, int ldw, long long strideW,
+                          const float* bias, long long strideBias, void* out, void* out_lo, int ldc, long long strideOut, int groups,
+                          int M, int N, int K, int act, float acc_scale, float plane_scale, mk_stream_t stream);
 
 /* Start of Transformer_self_att (att_layers/transformer.py:92-95): xs = x + pe (fp32 stream) and an
  * lp copy into columns [0,C) of a [rows, ld_cat] buffer.  x lp [G][rows, C]; pe fp32 [npix, C] or NULL. */

@@ -39,7 +39,8 @@ SIGNATURES = {
     "mk_bordered_rows": ("l", "iii"),
     "mk_conv3x3": ("i", "pliplipilplplpiliiiiiiip"),
     "mk_conv3x3_split": ("i", "pplipplipilplppiliiiiiiffp"),
-    "mk_split_planes": ("i", "plfppp"),
+    "mk_split_planes": ("i", "plilfpplp"),
+    "mk_gemm_grouped_split": ("i", "ppilpilplppiliiiiiffp"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
     "mk_linattn_work_floats": ("l", "iiii"),
     "mk_linattn_kv": ("i", "pppiiiip"),

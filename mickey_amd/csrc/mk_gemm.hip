@@ -346,11 +346,14 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
 
 // fp32 -> two fp16 planes, x * scale = hi + lo (22 mantissa bits); |x * scale| is saturated at fp16's largest finite value
 namespace {
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long n4, float scale,
-                                                           uint2* __restrict__ hi, uint2* __restrict__ lo) {
-  const long long i = blockIdx.x * 256LL + threadIdx.x;
-  if (i >= n4) return;
-  const f32x4 x = __builtin_nontemporal_load((const f32x4*)src + i) * scale;
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long rows, int cols4, long long ld_src4,
+                                                           float scale, uint2* __restrict__ hi, uint2* __restrict__ lo, long long ld_dst4) {
+  const long long t = blockIdx.x * 256LL + threadIdx.x;
+  if (t >= rows * cols4) return;
+  const long long r = t / cols4;
+  const int c = (int)(t - r * cols4);
+  const long long i = r * ld_dst4 + c;
+  const f32x4 x = __builtin_nontemporal_load((const f32x4*)src + r * ld_src4 + c) * scale;
   f16x4 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -363,14 +366,31 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }
 }  // namespace
 
-int mk_split_planes(const float* src, long long n, float scale, void* hi, void* lo, mk_stream_t stream) {
-  MK_CHECK_ARG(src && hi && lo && n > 0 && n % 4 == 0, "mk_split_planes: need n %% 4 == 0 and non-null pointers");
+int mk_split_planes(const float* src, long long rows, int cols, long long ld_src, float scale, void* hi, void* lo,
+                    long long ld_dst, mk_stream_t stream) {
+  MK_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= cols &&
+                   ld_dst >= cols, "mk_split_planes: cols / ld_src / ld_dst must be multiples of 4 and ld >= cols");
   MK_CHECK_ARG((((uintptr_t)src | (uintptr_t)hi * 2 | (uintptr_t)lo * 2) & 15) == 0, "mk_split_planes: src must be 16-byte, planes 8-byte aligned");
-  const long long n4 = n / 4;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n4, scale,
-                     (uint2*)hi, (uint2*)lo);
+  const long long n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, cols / 4,
+                     ld_src / 4, scale, (uint2*)hi, (uint2*)lo, ld_dst / 4);
   MK_CHECK_LAUNCH();
   return MK_OK;
+}
+
+int mk_gemm_grouped_split(const void* A_hi, const void* A_lo, int lda, long long strideA, const void* W, int ldw, long long strideW,
+                          const float* bias, long long strideBias, void* out, void* out_lo, int ldc, long long strideOut, int groups,
+                          int M, int N, int K, int act, float acc_scale, float plane_scale, mk_stream_t stream) {
+  GemmParams p = {};
+  p.A = A_hi; p.A_lo = A_lo; p.W = W; p.M = M; p.N = N; p.K = 3 * K; p.lda = lda; p.ldw = ldw;
+  p.npass = 3; p.acc_scale = acc_scale;
+  p.strideA_g = strideA; p.strideW_g = strideW; p.strideBias_g = strideBias; p.strideOut_g = strideOut;
+  p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = ldc;
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; } else { p.out_f32 = (float*)out; }
+  if (int e = check_common(p, MK_F16)) return e;
+  MK_CHECK_ARG(A_lo && out && groups > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldc % 4 == 0 && ldc >= N,
+               "mk_gemm_grouped_split: bad args (K must be a multiple of %d)", BK);
+  return launch<A_DENSE>(p, groups, MK_F16, (hipStream_t)stream);
 }
 
 int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,

@@ -310,8 +310,18 @@ struct Stager {
   __device__ __forceinline__ void issue(const GemmParams& p, char* sA, char* sW, int kt) const {
     const int k0 = kt * KT<T>;
     if (AMODE == A_DENSE) {
+      // split operands (mk_gemm_grouped_split): three sweeps over the K columns of A -- sweep 0 reads the LO plane
+      const T* const ah = A;
+      const T* const al = Alo;
+      const T* base = ah;
+      int kk = k0;
+      if (p.npass > 1) {
+        const int kp = p.K / 3, sweep = k0 / kp;
+        kk = k0 - sweep * kp;
+        base = sweep == 0 ? al : ah;
+      }
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) glds16(A + aoff[j] + k0, sA + (wave * AJ + j) * 1024);
+      for (int j = 0; j < AJ; ++j) glds16(base + aoff[j] + kk, sA + (wave * AJ + j) * 1024);
     } else {
       // wave-uniform: which sweep (split operands) / source / tap does this K tile belong to
       const int kc = 9 * p.C1;
@@ -600,7 +610,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
   float2 prm[8];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) prm[mi] = LN ? lnp[wm * 128 + mi * 16 + fr] : make_float2(1.f, 0.f);
-  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32 && !(CONV && p.out_lo));
+  const bool lp_out = EPI == MK_EPI_QKV || (EPI == MK_EPI_STORE && !p.out_f32 && !p.out_lo);
   if (lp_out) {
     int which = 0, head = 0;
     if (EPI == MK_EPI_QKV) {
@@ -763,7 +773,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           f32x4 v = acc[half * 4 + mi][ni];
-          if (CONV && p.npass > 1) {   // split-operand conv: undo the planes' power-of-two scaling
+          if (EPI == MK_EPI_STORE && p.npass > 1) {   // split operands: undo the planes' power-of-two scaling
             const float sc = p.acc_scale;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= sc;
@@ -851,7 +861,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           if (ok) x += *(const f32x4*)(p.pos + (long long)(1 + tok) * p.N + n);
           if (SPLIT) emit_row(xrow, (T*)p.xh + xrow * p.ldxs + n, (T*)p.xl + xrow * p.ldxs + n, x, ok);
           else if (ok) *(f32x4*)(p.out_f32 + xrow * p.ldc + n) = x;
-        } else if (CONV && p.out_lo) {   // split-operand conv chain: the next conv's (hi, lo) planes, 8 bytes per lane each
+        } else if (EPI == MK_EPI_STORE && p.out_lo) {   // split-operand chain: the next contraction's (hi, lo) planes, 8 bytes per lane each
           const float ps = p.plane_scale;
           f16x4 oh, ol;
 #pragma unroll

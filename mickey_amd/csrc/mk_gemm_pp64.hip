@@ -95,6 +95,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   auto dma_a1 = [&](int s, int j) {
     char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
     if (AMODE == A_DENSE) {
+      if constexpr (KIND == 0) {   // plain kernel: may run with split operands (mk_gemm_grouped_split): sweep 0 reads the LO plane
+        if (p.npass > 1) {
+          const int nkp = nk / 3, sweep = s >= 2 * nkp ? 2 : (s >= nkp ? 1 : 0);
+          const T* base = sweep == 0 ? (const T*)p.A_lo + (long long)g * p.strideA_g : A;
+          glds16_sv(base + (s - sweep * nkp) * BK, aoff[j], dst);
+          return;
+        }
+      }
       glds16_sv(A + s * BK, aoff[j], dst);
     } else {
       glds16_sv(cbase, ctap < 9 ? aoff[j] : aoff2[j], dst);   // the caller advances behind the 4th piece

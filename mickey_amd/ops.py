@@ -203,11 +203,36 @@ SPLIT_ACT_SCALE, SPLIT_W_SCALE = 64.0, 1024.0   # powers of two: activations up 
 
 
 def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
-    """fp32 tensor -> fp16 planes with x * scale = hi + lo (mk_split_planes); hi / lo: preallocated, same shape."""
-    assert x.dtype == torch.float32 and hi.dtype == torch.float16 and lo.dtype == torch.float16
-    assert x.is_contiguous() and hi.is_contiguous() and lo.is_contiguous() and hi.shape == x.shape == lo.shape
-    call("mk_split_planes", ptr(x), x.numel(), float(scale), ptr(hi), ptr(lo), stream())
+    """fp32 tensor -> fp16 planes with x * scale = hi + lo (mk_split_planes); hi / lo: preallocated, same shape.  x, hi, lo
+    may be column blocks of wider row-major matrices (views whose last dimension is contiguous and whose rows are
+    equidistant, e.g. t[..., :C])."""
+    assert x.dtype == torch.float32 and hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == x.shape == lo.shape
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+
+    def ld(t):   # row stride of a [..., cols] view with uniformly spaced rows
+        assert t.stride(-1) == 1
+        lead = t.stride(-2) if t.dim() > 1 else cols
+        for d in range(t.dim() - 2):   # leading dims must continue the same row spacing
+            assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "rows must be equidistant"
+        return lead
+    assert ld(hi) == ld(lo)
+    call("mk_split_planes", ptr(x), rows, cols, ld(x), float(scale), ptr(hi), ptr(lo), ld(hi), stream())
     return hi, lo
+
+
+def gemm_grouped_split(a, w, bias, out, groups, M, N, K, lda, ldc, stride_a, stride_w, stride_bias, stride_out, act=ACT_NONE):
+    """mk_gemm_grouped_split: a = (hi, lo) fp16 planes [groups, M, lda], w fp16 [groups, N, 3 K]; out fp32 or a (hi, lo) pair."""
+    ah, al = a
+    assert w.dtype == torch.float16 and w.shape[-1] == 3 * K
+    if isinstance(out, (tuple, list)):
+        oh, ol = out
+    else:
+        oh, ol = out, None
+        assert out.dtype == torch.float32
+    call("mk_gemm_grouped_split", ptr(ah), ptr(al), lda, stride_a, ptr(w), 3 * K, stride_w, ptr(bias), stride_bias, ptr(oh), ptr(ol),
+         ldc, stride_out, groups, M, N, K, act, 1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), SPLIT_ACT_SCALE, stream())
+    return out
 
 
 def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, stride_in1=0, stride_in2=0,

@@ -166,17 +166,38 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     hid = ws.get("att_hid", (G, M, 2 * C), lp, dev)
     x4 = ws.get("att_out" + geo, (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
     nl = len(W.att)
+    if split:
+        # the layers' small linears on split operands too (fp32 MFMA: 4.9 ms per 32 pairs; split: the conversions below + 12
+        # HBM-bound GEMMs): planes of `cat` (its two column halves are rewritten at different times), of `msg`, and `hid`
+        # written as planes by the GEMM that produces it
+        catp = (ws.get("att_cat_hi", (G, M, 2 * C), torch.float16, dev), ws.get("att_cat_lo", (G, M, 2 * C), torch.float16, dev))
+        msgp = (ws.get("att_msg_hi", (G, M, C), torch.float16, dev), ws.get("att_msg_lo", (G, M, C), torch.float16, dev))
+        hidp = (ws.get("att_hid_hi", (G, M, 2 * C), torch.float16, dev), ws.get("att_hid_lo", (G, M, 2 * C), torch.float16, dev))
     for li, lay in enumerate(W.att):
-        ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
-        ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
-        ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
-        ops.gemm_grouped(msg, lay.merge_w, None, mrg, G, M, C, C, C, C, C, M * C, C * C, 0, M * C)
-        ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
-                      wgroup_rows=M)
-        ops.gemm_grouped(cat, lay.mlp0_w, None, hid, G, M, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 4 * C * C, 0,
-                         M * 2 * C, act=ops.ACT_RELU)
-        ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
         last = li == nl - 1
+        if split:
+            ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C])
+            ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 3 * C, 0, M * 3 * C)
+            ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
+            ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
+            ops.split_planes(msg, msgp[0], msgp[1])
+            ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 3 * C, 0, M * C)
+            ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
+                          wgroup_rows=M)
+            ops.split_planes(cat[:, :, C:], catp[0][:, :, C:], catp[1][:, :, C:])
+            ops.gemm_grouped_split(catp, lay.mlp0_w, None, hidp, G, M, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 2 * C * 3 * 2 * C, 0,
+                                   M * 2 * C, act=ops.ACT_RELU)
+            ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 3 * 2 * C, 0, M * C)
+        else:
+            ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
+            ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
+            ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
+            ops.gemm_grouped(msg, lay.merge_w, None, mrg, G, M, C, C, C, C, C, M * C, C * C, 0, M * C)
+            ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
+                          wgroup_rows=M)
+            ops.gemm_grouped(cat, lay.mlp0_w, None, hid, G, M, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 4 * C * C, 0,
+                             M * 2 * C, act=ops.ACT_RELU)
+            ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
         ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=x4 if last else cat, ldo=C if last else 2 * C, resid=xs,
                       rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None)
     # ---- resblock4 ----

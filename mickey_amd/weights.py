@@ -170,9 +170,10 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
         lay = DeviceWeights()
         def stk(name):
             return torch.stack([sd[e + h + ".att_layer.layers.%d.%s" % (l, name)].float() for h in HEADS])
-        lay.qkv_w = lp(torch.cat([stk("q_proj.weight"), stk("k_proj.weight"), stk("v_proj.weight")], 1))  # [4,384,128]
-        lay.merge_w = lp(stk("merge.weight"))
-        lay.mlp0_w, lay.mlp2_w = lp(stk("mlp.0.weight")), lp(stk("mlp.2.weight"))
+        # (split mode: the same [W_hi | W_lo | W_hi] K layout as the convs, for mk_gemm_grouped_split)
+        lay.qkv_w = convw(torch.cat([stk("q_proj.weight"), stk("k_proj.weight"), stk("v_proj.weight")], 1))  # [4,384,128]
+        lay.merge_w = convw(stk("merge.weight"))
+        lay.mlp0_w, lay.mlp2_w = convw(stk("mlp.0.weight")), convw(stk("mlp.2.weight"))
         lay.n1w, lay.n1b = f32(stk("norm1.weight")), f32(stk("norm1.bias"))
         lay.n2w, lay.n2b = f32(stk("norm2.weight")), f32(stk("norm2.bias"))
         W.att.append(lay)

@@ -621,6 +621,37 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
     assert float((back - out.double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("M,N,K,lda", [(500, 128, 128, 256), (40000, 384, 128, 256), (40000, 256, 256, 256), (3000, 128, 256, 256)])
+def test_grouped_gemm_split_is_fp32_grade(M, N, K, lda):
+    """mk_gemm_grouped_split (the heads' small linears in AMD.HEADS_DTYPE: split): fp32 A [G, M, lda] as (hi, lo) planes -- also
+    converted as two column blocks at different times, as the pipeline does with `cat` -- times fp32 weights in the
+    [W_hi | W_lo | W_hi] layout, both kernels (128x128; 256x256 ping-pong for the 40000-row cases), fp32 output and the
+    plane-output form with ReLU; against fp64."""
+    from mickey_amd import ops, weights
+    dev = _dev()
+    ops.gemm_set_tile(0)
+    G = 4
+    a = (torch.randn((G, M, lda), generator=g(1)) * torch.exp(torch.randn((G, M, 1), generator=g(2)))).to(dev)
+    w = (torch.randn((G, N, K), generator=g(3)) / math.sqrt(K))
+    ws = weights.split_conv_weight(w).to(dev).contiguous()
+    ah, al = torch.empty_like(a, dtype=torch.float16), torch.empty_like(a, dtype=torch.float16)
+    half = lda // 2
+    ops.split_planes(a[:, :, :half], ah[:, :, :half], al[:, :, :half])
+    ops.split_planes(a[:, :, half:], ah[:, :, half:], al[:, :, half:])
+    assert float((ah.double() + al.double() - a.double() * ops.SPLIT_ACT_SCALE).abs().max()) <= 2.0 ** -21 * float(a.abs().max()) * 64 + 1e-7
+    out = torch.empty((G, M, N), device=dev, dtype=torch.float32)
+    ops.gemm_grouped_split((ah, al), ws, None, out, G, M, N, K, lda, N, M * lda, N * 3 * K, 0, M * N)
+    ref64 = torch.einsum("gmk,gnk->gmn", a[:, :, :K].double(), w.to(dev).double())
+    ref32 = torch.einsum("gmk,gnk->gmn", a[:, :, :K], w.to(dev))
+    e, e32 = rel(out, ref64), rel(ref32, ref64)
+    print("split grouped GEMM vs fp64 %.2e (torch fp32 %.2e)" % (e, e32))
+    assert e < 2e-6 and e < 4 * e32 + 2e-7
+    oh, ol = torch.empty((G, M, N), device=dev, dtype=torch.float16), torch.empty((G, M, N), device=dev, dtype=torch.float16)
+    ops.gemm_grouped_split((ah, al), ws, None, (oh, ol), G, M, N, K, lda, N, M * lda, N * 3 * K, 0, M * N, act=ops.ACT_RELU)
+    back = (oh.double() + ol.double()) / ops.SPLIT_ACT_SCALE
+    assert float((back - F.relu(out).double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
+
+
 def test_grouped_gemm():
     from mickey_amd import ops
     dev = _dev()
