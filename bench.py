@@ -37,7 +37,30 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
-TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/r04_pmc_traffic.json"
+
+
+STAGE_ROLES = {"encoder_gemm": ("encoder_gemm",), "attention": ("attention",), "conv_gemm": ("conv_gemm",),
+               "matcher": ("matcher_",), "sampler": ("sampler",), "layernorm": ("layernorm",)}
+
+
+def pmc_stage_traffic(batch):
+    """{stage: HBM-side bytes per forward} from the same committed counter file (per kernel role, summed over the launches of
+    one forward), under the same conditions as pmc_traffic(): same kernel sources, same batch; else {}."""
+    from mickey_amd import build as mkbuild
+    path = os.path.join(ROOT, TRAFFIC_SOURCE)
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    if d.get("source_hash") != mkbuild.source_hash() or d.get("batch") != batch:
+        return {}
+    out = {}
+    for stage, prefixes in STAGE_ROLES.items():
+        vals = [v["bytes_per_forward"] for k, v in d.get("roles", {}).items()
+                if any(k.startswith(p) for p in prefixes) and v.get("bytes_per_forward") is not None]
+        if vals:
+            out[stage] = sum(vals)
+    return out
 
 
 def pmc_traffic(batch):
@@ -495,6 +518,12 @@ def roofline_entry(stages, by, B, dtype, model):
         return None
     tf = g["work"] / (g["ms"] * 1e-3) / 1e12
     traffic, why = pmc_traffic(B)
+    st_traffic = pmc_stage_traffic(B)
+    for st in stages:   # per stage: HBM-side bytes per step from the PMC passes next to the algorithmic bytes (bandwidth-bound stages)
+        if st["stage"] in st_traffic:
+            st["traffic_mb_per_step"] = st_traffic[st["stage"]] / 1e6
+            if st.get("algorithmic_mb_per_step"):
+                st["traffic_over_algorithmic"] = st["traffic_mb_per_step"] / st["algorithmic_mb_per_step"]
     roof = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (encoder linears: qkv, proj, fc1, fc2, patch embed)" % dtype,
             "achieved": tf, "peak": PEAK_MFMA_TF, "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TF,
             "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss side, PMC)",

@@ -82,20 +82,28 @@ __device__ __forceinline__ void load_operand(float (&a)[CMAX / 2], const float* 
 // then holds that unit's ~2 MB of descriptors.  (Dealt naively, every XCD serves 8 pairs at a time, thrashes its L2 and
 // pulls 1.9 GB of 128-byte pieces from memory per pass: measured 1.9 ms instead of 0.4.)  The grid is padded to a
 // multiple of 8 units; returns false for padding.
+// Y_FASTEST: consecutive workgroups of a unit walk the y index (the column chunks of the split passes) first: the workgroups
+// in flight at one time then cover WHOLE rows of the output between them (kernels that write [rows, n1] matrices tile by tile:
+// a wave's 256-byte row pieces meet their neighbours' in the same DRAM pages while those are open).
+template <bool Y_FASTEST = false>
 __device__ __forceinline__ bool decode_unit_grid(int gx, int gy, int nunits, int& bx, int& by, int& unit) {
   const int L = blockIdx.x, per = gx * gy;
+  int within;
   if (nunits < 8) {   // too few units to give every XCD one: spread each unit over the whole chip instead
     unit = L / per;
-    const int within = L - unit * per;
+    within = L - unit * per;
+  } else {
+    const int xcd = L & 7, slot = L >> 3;
+    unit = (slot / per) * 8 + xcd;
+    within = slot - (slot / per) * per;
+  }
+  if (Y_FASTEST) {
+    by = within % gy;
+    bx = within / gy;
+  } else {
     bx = within % gx;
     by = within / gx;
-    return unit < nunits;
   }
-  const int xcd = L & 7, slot = L >> 3;
-  unit = (slot / per) * 8 + xcd;
-  const int within = slot - (slot / per) * per;
-  bx = within % gx;
-  by = within / gx;
   return unit < nunits;
 }
 
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits) {
   __shared__ __attribute__((aligned(16))) float stage[4][RT * 64];
   int bx, by, b;
-  if (!decode_unit_grid(gx, NCHUNK_S, nunits, bx, by, b)) return;
+  if (!decode_unit_grid<true>(gx, NCHUNK_S, nunits, bx, by, b)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rb = bx * 4 + wave, i0 = rb * RT;

@@ -7,7 +7,7 @@
 #      (FETCH_SIZE / WRITE_SIZE, read by bench.py when its source hash matches) and gpurun_out/${TAG}_pmc_busy.json
 #      (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE)
 # Copy what should be judged from gpurun_out/ to profiles/.
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 STEPS_BENCH=${STEPS_BENCH:-20}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -45,6 +45,7 @@ def role(name):
         return {0: "gemm_plain(head linears)", 1: "encoder_gemm_consumer(qkv,fc1)", 2: "encoder_gemm_producer(proj,fc2,patch)",
                 3: "encoder_gemm_producer_f32out"}[kind]
     for key, r in (("attn_", "attention"), ("layernorm", "layernorm"), ("lse_partial", "matcher_pass1"), ("dual_softmax_apply", "matcher_pass2"),
+                   ("lse_split", "matcher_pass1"), ("split_apply", "matcher_pass2"), ("dsc_split", "matcher_planes"), ("lse_final", "matcher_merge"),
                    ("exprace", "sampler"), ("ransac_hyp", "hypotheses"), ("gemm_kernel", "gemm_128")):
         if key in name:
             return r
@@ -62,7 +63,7 @@ def collect(tag, counters):
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
-meta = {"source_hash": B.source_hash(), "batch": 32, "command": "bench.py --steps 1 --warmup 1 --lean --no-kernel-events (2 forwards)",
+meta = {"source_hash": B.source_hash(), "batch": 32, "forwards": 2, "command": "bench.py --steps 1 --warmup 1 --lean --no-kernel-events (2 forwards)",
         "note": "rocprofv3 --kernel-trace --pmc <one group>, one pass per group; values are means per launch; FETCH_SIZE / WRITE_SIZE "
                 "in KiB as reported (gfx950: a streaming read fetches 2x what FETCH_SIZE says, MI355X_MICROARCH.md)"}
 traffic = dict(meta)
@@ -72,6 +73,9 @@ for k in sorted(set(f) | set(w)):
     fv, wv = f[k].get("FETCH_SIZE", []), w[k].get("WRITE_SIZE", [])
     roles[k] = {"launches": len(fv) or len(wv), "FETCH_SIZE_KiB_per_launch": sum(fv) / len(fv) if fv else None,
                 "WRITE_SIZE_KiB_per_launch": sum(wv) / len(wv) if wv else None}
+for k, v in roles.items():   # HBM-side bytes of the role per FORWARD: (2 x FETCH_SIZE + WRITE_SIZE) KiB x launches / forwards
+    if v["FETCH_SIZE_KiB_per_launch"] is not None and v["WRITE_SIZE_KiB_per_launch"] is not None:
+        v["bytes_per_forward"] = (2.0 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024.0 * v["launches"] / meta["forwards"]
 traffic["roles"] = roles
 enc = [k for k in roles if k.startswith("encoder_gemm")]
 if enc:
