@@ -24,6 +24,10 @@ int mk_gemm_set_tile(int mode);
  * kernel (64 queries per wave; A/B partner).  Process-wide; for benchmarks and tests. */
 int mk_attn_set_mode(int mode);
 
+/* mk_dual_softmax_split, pass 2 (the writer of scores / kp_scores / final_scores): column chunks per 32-row block = waves
+ * that share one block's rows; 0 = one pair of column tiles per wave (default), 8 = round 4's first version (A/B). */
+int mk_dual_softmax_set_chunks(int chunks);
+
 /* mk_sinkhorn: n > 0 = n image pairs iterated together through all Sinkhorn iterations (so that their coupling matrices could
  * stay in the 256-MB Infinity Cache between the 20 passes; measured no faster: profiles/r04c_bench_matcher.txt), 0 = the
  * whole batch per pass with non-temporal reads (default). */

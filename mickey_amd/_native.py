@@ -72,6 +72,7 @@ DEV_SIGNATURES = {
     "mk_gemm_set_tile": ("i", "i"),
     "mk_attn_set_mode": ("i", "i"),
     "mk_sinkhorn_set_group": ("i", "i"),
+    "mk_dual_softmax_set_chunks": ("i", "i"),
 }
 
 _lib = None

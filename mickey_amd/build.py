@@ -30,6 +30,7 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fno-trapping-math", "-fno-slp-vectorize"] +
                (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []) +
                (["-DMK_ATTN_LP_DBG"] if os.environ.get("MK_ATTN_LP_DBG") else []),
+               "mk_matcher.hip": (["-DMK_MATCHER_ALIGN_PROBE"] if os.environ.get("MK_MATCHER_ALIGN_PROBE") else []),
                "mk_input.hip": ["-ffp-contract=off"],   # cv2-exact coordinates: (d + 0.5) * scale - 0.5 must not become an fma
                # the ping-pong GEMM's epilogues are VALU-bound (both waves of a SIMD drain while the matrix pipe idles): SLP packs the
                # (sum, sum of squares) pairs of the row statistics into v_pk_add_f32, which keeps the DPP steps of their 16-lane

@@ -419,10 +419,10 @@ template <int VEC>   // floats per lane of an output store: 4 when the output ro
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_split_apply_kernel(
     const uint4* __restrict__ P0, const uint4* __restrict__ P1, float scale2, const float* __restrict__ scr0,
     const float* __restrict__ scr1, const float* __restrict__ lse2, float* __restrict__ scores, float* __restrict__ kp,
-    float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits) {
+    float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits, int nchunk) {
   __shared__ __attribute__((aligned(16))) float stage[4][RT * 64];
   int bx, by, b;
-  if (!decode_unit_grid<true>(gx, NCHUNK_S, nunits, bx, by, b)) return;
+  if (!decode_unit_grid<true>(gx, nchunk, nunits, bx, by, b)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int rb = bx * 4 + wave, i0 = rb * RT;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* st = stage[wave];
   SplitOperand a, bq;
   a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
-  const int per = (ntb + NCHUNK_S - 1) / NCHUNK_S;
+  const int per = (ntb + nchunk - 1) / nchunk;
   const int jt0 = by * per, jt1 = min(ntb, jt0 + per);
   float lr[16], s0[16];
 #pragma unroll
@@ -479,6 +479,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int it = 0; it < RT / RPI; ++it) {
         const int row = dr + RPI * it, i = i0 + row, j = jbase + dc;
         const VT val = *(const VT*)(st + row * 64 + dc);
+#ifdef MK_MATCHER_ALIGN_PROBE   // TIMING PROBE, WRONG RESULTS: every row piece shifted so that it starts on a 128-byte line
+        {
+          const int e0 = (int)((((long long)b * n0 + i) * n1) & 31);
+          const int ja = j - e0;
+          if (i < n0 && ja >= 0 && j + VEC <= jlim) *(VT*)(out + ((long long)b * n0 + i) * n1 + ja) = val;
+          continue;
+        }
+#endif
         if (i < n0 && j + VEC <= jlim) *(VT*)(out + ((long long)b * n0 + i) * n1 + j) = val;   // (jlim is a multiple of VEC)
       }
     }
@@ -745,6 +753,7 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 
 }  // namespace
 
+static int g_ds_chunk2 = 0;   // dual softmax (split path): column chunks of pass 2 per row block (0 = one pair of tiles per wave)
 static int g_sk_group = 0;   // Sinkhorn: pairs iterated together (0: the whole batch per pass with non-temporal reads)
 
 extern "C" {
@@ -835,16 +844,20 @@ int mk_dual_softmax_split(const float* dsc0, const float* dsc1, const float* scr
                      dustbin * LOG2E, n0, n1, nmax, nrb, NCHUNK_S);
   MK_CHECK_LAUNCH();
   if (scores || kp_scores || final_scores) {
+    // pass 2 is a WRITER: the fewer output rows the chip has in flight at a time, the more of its 256-byte row pieces meet open
+    // DRAM pages.  g_ds_chunk2 column chunks per row block (dev knob; 0 = one pair of column tiles per wave: the smallest window)
+    const int nchunk2 = g_ds_chunk2 > 0 ? g_ds_chunk2 : (ntb + 1) / 2;
+    const dim3 g2((unsigned)gx * nchunk2 * ((B + 7) / 8 * 8));
     const bool a16 = ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 15) == 0);
     if ((n1 & 3) == 0 && a16)
-      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<4>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
-                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<4>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
     else if ((n1 & 1) == 0 && ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 7) == 0))
-      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<2>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
-                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<2>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
     else
-      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<1>, g, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
-                         final_scores, n0, n1, nmax, nrb, ntb, gx, B);
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<1>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
     MK_CHECK_LAUNCH();
   }
   return MK_OK;
@@ -917,6 +930,11 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const f
                        final_scores ? final_scores + (long long)b0 * n0 * n1 : nullptr, n0, n1, ldz, ldu);
     MK_CHECK_LAUNCH();
   }
+  return MK_OK;
+}
+
+int mk_dual_softmax_set_chunks(int chunks) {
+  g_ds_chunk2 = chunks;
   return MK_OK;
 }
 

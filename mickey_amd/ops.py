@@ -315,6 +315,11 @@ def dual_softmax(dsc0, dsc1, scr0=None, scr1=None, temperature=0.1, dustbin=None
     return scores, kp, fin
 
 
+def dual_softmax_set_chunks(chunks):
+    """Dev knob (mickey_hip_dev.h): column chunks per row block in pass 2 of mk_dual_softmax_split (0 = default)."""
+    call("mk_dual_softmax_set_chunks", int(chunks))
+
+
 def sinkhorn_set_group(pairs):
     """Dev knob (mickey_hip_dev.h): pairs iterated together by mk_sinkhorn (0 = batch-wide, non-temporal reads: default)."""
     call("mk_sinkhorn_set_group", int(pairs))

@@ -54,6 +54,6 @@ for d in sorted(glob.glob("/tmp/pc_*")):
         cyc = sum(r[1] for r in rows) / len(rows)
         busy = sum(r[2] for r in rows) / len(rows)
         out[tag] = {"dispatches": len(rows), "mean_us": ns / 1e3, "kcycles": cyc / 1e3, "clock_GHz": cyc / ns, "mfma_busy_frac": busy / cyc}
-json.dump(out, open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r03_pmc_clock.json", "w"), indent=1)
+json.dump(out, open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/%s_pmc_clock.json" % os.environ.get("TAG", "r04"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
