@@ -771,10 +771,12 @@ def test_split_fp16_correlation_is_fp32_grade():
     assert errs["split"] < 3 * max(errs["exact"], errs["oracle_fp32"])
 
 
-@pytest.mark.parametrize("B,C,n0,n1", [(3, 64, 77, 200), (9, 128, 97, 64), (1, 32, 33, 31)])
-def test_dual_softmax_other_shapes(B, C, n0, n1):
+@pytest.mark.parametrize("B,C,n0,n1,split", [(3, 64, 77, 200, False), (9, 128, 97, 64, False), (1, 32, 33, 31, False),
+                                            (9, 128, 97, 64, True), (11, 128, 70, 196, True), (2, 128, 33, 31, True)])
+def test_dual_softmax_other_shapes(B, C, n0, n1, split):
     """Descriptor widths below 128 (the generic-C instantiation), ragged n0 != n1 not multiples of 32, and B >= 8 (the
-    XCD-local workgroup decode) against the oracle."""
+    XCD-local workgroup decode) against the oracle; split path: output rows 16-byte aligned (n1 % 4 == 0: 16-byte stores),
+    8-byte aligned and odd (single floats), fewer column tiles than a wave's pair."""
     from mickey_amd import ops
     from oracle import mickey_oracle as O
     dev = _dev()
@@ -784,10 +786,15 @@ def test_dual_softmax_other_shapes(B, C, n0, n1):
     s1 = torch.rand((B, 1, n1), generator=g(34)) / n1
     ref = O.dual_softmax(d0, d1, 1.0, 0.1)
     kp_ref = torch.matmul(s0.transpose(2, 1), s1)
-    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 1.0)
+    sc, kp, fin = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 1.0, split=split)
     assert rel(sc, ref) < 1e-5, rel(sc, ref)
     assert torch.equal(kp.cpu(), kp_ref)
     assert rel(fin, ref * kp_ref) < 1e-5
+    if split:   # the dev knob of pass 2 (column chunks per row block) changes the schedule, not a bit of the result
+        ops.dual_softmax_set_chunks(3)
+        sc2, kp2, fin2 = ops.dual_softmax(d0.to(dev), d1.to(dev), s0.to(dev), s1.to(dev), 0.1, 1.0, split=True)
+        ops.dual_softmax_set_chunks(0)
+        assert torch.equal(sc2, sc) and torch.equal(fin2, fin) and torch.equal(kp2, kp)
 
 
 def test_matcher_golden(golden):
