@@ -481,7 +481,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
           f16x4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float sv = fminf(v[e] * ps, 65504.f);   // (post-ReLU or small: only the upper end can overflow fp16)
+            const float sv = fminf(fmaxf(v[e] * ps, -65504.f), 65504.f);   // saturate at fp16's largest finite value
             oh[e] = (_Float16)sv;
             ol[e] = (_Float16)(sv - (float)oh[e]);
           }
@@ -866,7 +866,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           f16x4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float sv = fminf(val[e] * ps, 65504.f);
+            const float sv = fminf(fmaxf(val[e] * ps, -65504.f), 65504.f);
             oh[e] = (_Float16)sv;
             ol[e] = (_Float16)(sv - (float)oh[e]);
           }

@@ -221,7 +221,8 @@ def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
     return hi, lo
 
 
-def gemm_grouped_split(a, w, bias, out, groups, M, N, K, lda, ldc, stride_a, stride_w, stride_bias, stride_out, act=ACT_NONE):
+def gemm_grouped_split(a, w, bias, out, groups, M, N, K, lda, ldc, stride_a, stride_w, stride_bias, stride_out, act=ACT_NONE,
+                       w_scale=SPLIT_W_SCALE):
     """mk_gemm_grouped_split: a = (hi, lo) fp16 planes [groups, M, lda], w fp16 [groups, N, 3 K]; out fp32 or a (hi, lo) pair."""
     ah, al = a
     assert w.dtype == torch.float16 and w.shape[-1] == 3 * K
@@ -231,12 +232,12 @@ def gemm_grouped_split(a, w, bias, out, groups, M, N, K, lda, ldc, stride_a, str
         oh, ol = out, None
         assert out.dtype == torch.float32
     call("mk_gemm_grouped_split", ptr(ah), ptr(al), lda, stride_a, ptr(w), 3 * K, stride_w, ptr(bias), stride_bias, ptr(oh), ptr(ol),
-         ldc, stride_out, groups, M, N, K, act, 1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), SPLIT_ACT_SCALE, stream())
+         ldc, stride_out, groups, M, N, K, act, 1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, stream())
     return out
 
 
 def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, stride_in1=0, stride_in2=0,
-                  stride_w=0, stride_bias=0, stride_out=0, out_bordered=False):
+                  stride_w=0, stride_bias=0, stride_out=0, out_bordered=False, w_scale=SPLIT_W_SCALE):
     """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes, w fp16 [.., Cout, 3 K]; out: an fp32 tensor, or
     a (hi, lo) pair of fp16 planes = the operand form of the next split conv (no fp32 round trip, no mk_split_planes pass)."""
     assert w.dtype == torch.float16
@@ -250,7 +251,7 @@ def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE,
         assert out.dtype == torch.float32
     call("mk_conv3x3_split", ptr(h1), ptr(l1), stride_in1, C1, ptr(h2), ptr(l2), stride_in2, C2, ptr(w), w.shape[-1], stride_w,
          ptr(bias), stride_bias, ptr(oh), ptr(ol), Cout, stride_out, groups, nimg, H, W, act, int(out_bordered),
-         1.0 / (SPLIT_ACT_SCALE * SPLIT_W_SCALE), SPLIT_ACT_SCALE, stream())
+         1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, stream())
     return out
 
 

@@ -110,6 +110,9 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     geo = "_%d_%d_%d" % (nimg, gh, gw)   # bordered buffers: the workspace key carries the geometry (see encoder_forward)
     split = bool(getattr(W, "heads_split", False))   # 3x3 convs on split fp16 operands inside the fp32 head pipeline
 
+    def wsc(w):   # power-of-two scale of a split weight tensor's planes (weights.prepare)
+        return W.wscale[w.data_ptr()]
+
     def planes(name, x):
         """fp32 (bordered) activation -> its (hi, lo) fp16 planes, the operand form of mk_conv3x3_split; border rows are
         zeros in x, hence in both planes."""
@@ -130,10 +133,10 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
             # conv -> conv inside the stack: the epilogue writes the next conv's (hi, lo) operand planes directly (no fp32
             # round trip, no mk_split_planes pass); only the stack's output (read by the row-wise attention kernels) is fp32
             hp = plane_pair("rb%d_h" % bi, (G, R, co))
-            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in,
+            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in, w_scale=wsc(rb.w1),
                               stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
             xo = ws.get("rb%d_x" % bi + geo, (G, M, co), lp, dev) if last else plane_pair("rb%d_x" % bi, (G, R, co))
-            ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in,
+            ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in, w_scale=wsc(rb.w2),
                               stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
                               stride_out=(M if last else R) * co, out_bordered=not last)
             if not last:
@@ -177,17 +180,19 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
         last = li == nl - 1
         if split:
             ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C])
-            ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 3 * C, 0, M * 3 * C)
+            ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 3 * C, 0, M * 3 * C,
+                                   w_scale=wsc(lay.qkv_w))
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
             ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
             ops.split_planes(msg, msgp[0], msgp[1])
-            ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 3 * C, 0, M * C)
+            ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 3 * C, 0, M * C, w_scale=wsc(lay.merge_w))
             ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
                           wgroup_rows=M)
             ops.split_planes(cat[:, :, C:], catp[0][:, :, C:], catp[1][:, :, C:])
             ops.gemm_grouped_split(catp, lay.mlp0_w, None, hidp, G, M, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 2 * C * 3 * 2 * C, 0,
-                                   M * 2 * C, act=ops.ACT_RELU)
-            ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 3 * 2 * C, 0, M * C)
+                                   M * 2 * C, act=ops.ACT_RELU, w_scale=wsc(lay.mlp0_w))
+            ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 3 * 2 * C, 0, M * C,
+                                   w_scale=wsc(lay.mlp2_w))
         else:
             ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
@@ -209,15 +214,15 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     if split:
         x4h, x4l = planes("att_out", x4)
         h4p = plane_pair("rb4_h", (3, R, ck))
-        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C,
+        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C, w_scale=wsc(kpw.w1),
                           stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
         assert kpw.has_sc and dw.has_sc   # (weights.prepare gives the descriptor block identity shortcut columns in this mode)
-        ops.conv3x3_split(h4p, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU,
+        ops.conv3x3_split(h4p, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, w_scale=wsc(kpw.w2),
                           in2=(x4h[:3], x4l[:3]), C2=C, stride_in1=R * ck, stride_in2=R * C,
                           stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
         hdp = plane_pair("rb4_hd", (R, cd))
-        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hdp, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True)
-        ops.conv3x3_split(hdp, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE,
+        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hdp, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True, w_scale=wsc(dw.w1))
+        ops.conv3x3_split(hdp, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE, w_scale=wsc(dw.w2),
                           in2=(x4h[3], x4l[3]), C2=C)   # relu=False, mickey_extractor.py:246
     else:
         h4 = ws.get("rb4_h" + geo, (3, R, ck), lp, dev, zero=True)

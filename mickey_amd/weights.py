@@ -104,13 +104,28 @@ def prepare_encoder(sd, device, lp_dtype=torch.bfloat16, prefix=DINO_PREFIX, W=N
     return W
 
 
-def split_conv_weight(w, scale=1024.0):
+def split_weight_scale(w, target=1024.0):
+    """Power-of-two scale of a weight tensor's fp16 planes: `target` (2^10: keeps the lo plane of ordinary weights out of
+    fp16's subnormals), lowered for tensors with entries so large (BatchNorm folded over a tiny running variance) that
+    w * target would leave fp16's range."""
+    m = float(w.abs().max()) if w.numel() else 0.0
+    s = float(target)
+    while m * s > 32768.0 and s > 2.0 ** -14:
+        s *= 0.5
+    return s
+
+
+def split_conv_weight(w, scale=None):
     """[.., Cout, K] fp32 (BatchNorm folded) -> fp16 [.., Cout, 3 K] = [W_hi | W_lo | W_hi] of w * scale, w * scale = hi + lo:
-    the K layout mk_conv3x3_split sweeps (sweep 0 pairs the LO activation planes with W_hi, 1: hi x lo, 2: hi x hi)."""
+    the K layout mk_conv3x3_split sweeps (sweep 0 pairs the LO activation planes with W_hi, 1: hi x lo, 2: hi x hi).
+    scale: a power of two, default split_weight_scale(w); the caller passes the same value as `w_scale` to the kernel wrapper."""
+    scale = split_weight_scale(w) if scale is None else scale
     ws = w.float() * scale
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
-    return torch.cat([hi, lo, hi], -1)
+    out = torch.cat([hi, lo, hi], -1)
+    assert bool(torch.isfinite(out).all()), "weights do not fit fp16 planes"
+    return out
 
 
 def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True, heads_split=False):
@@ -124,9 +139,14 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
     W.heads_split = bool(heads_split)
     assert not W.heads_split or W.lp_heads == torch.float32, "split-operand convs sit in the fp32 head pipeline"
 
-    def convw(t):   # weights of a 3x3 conv (+ shortcut columns): operand type of the heads, or the split K layout
+    W.wscale = {}   # split mode: data_ptr of a split weight tensor -> the power-of-two scale of its planes
+
+    def convw(t):   # weights of a 3x3 conv (+ shortcut columns) / a head linear: operand type of the heads, or the split K layout
         if W.heads_split:
-            return split_conv_weight(t).to(device=dev).contiguous()
+            sc = split_weight_scale(t)
+            out = split_conv_weight(t, sc).to(device=dev).contiguous()
+            W.wscale[out.data_ptr()] = sc
+            return out
         return t.to(device=dev, dtype=W.lp_heads).contiguous()
 
     def lp(t):
