@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
 // The joint distribution is that of independent 24-bit uniforms per (row, cell) -- the sampler is unchanged, the RNG work
 // drops from 5 to ~1.3 Philox calls per cell.  Cells with p >= 0.0155 T (a few thousand per pair) take stage 2 for all
 // their rows.  Counter layout: z = (pair + pair_base) * 512 + {256 + row / 20 (stage 1) | row (stage 2)}.
-constexpr int PF_CPT = 4;         // cells per thread per iteration
+constexpr int PF_CPT = 3;         // cells per thread per iteration: 768 cells queue ~240 (cell, row) pairs = ONE dense round of stage 2
+                                  // (4 cells: 320 pairs = two rounds, the second a quarter full)
 constexpr int PF_QCAP = 2048;     // queued (cell, row) pairs per iteration (expected 320 + 20 per large-p cell)
 constexpr int PF_LCAP = 128;      // LDS candidate slots per row and block (expected ~20)
 constexpr int PF_MAXROWS = 48;   // LDS: rows x 1 KiB of candidates + 8 KiB queue <= 56 KiB
@@ -1075,7 +1076,11 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   MK_CHECK_LAUNCH();
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), ol = (unsigned)offset, oh = (unsigned)(offset >> 32);
   const int groups = (rows_per_pair + RG - 1) / RG;
+  // cell blocks per pair: 128 at the bench batch; small batches (one pair: 128 workgroups on a 256-CU part, each walking 29 k
+  // cells) take more, so that B * cb fills the chip a few times over.  The candidate SET does not depend on the split (the
+  // select kernel orders it), so a pair's draws do not depend on the batch it is in.
   int cb = CELL_BLOCKS;
+  while (cb < 1024 && (long long)B * cb < 2048) cb *= 2;
   if ((long long)cb * 256 > ncell) cb = (int)((ncell + 255) / 256);
   dim3 grid(cb, groups, B);
   // analytic threshold from the histogram of p, then ONE noise pass (collect)
