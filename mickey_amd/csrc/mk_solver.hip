@@ -595,11 +595,13 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
                                                          float* __restrict__ Rh, float* __restrict__ th,
                                                          float* __restrict__ score, int* __restrict__ idx3, int it_ransac, int k,
                                                          int nsplit, long long set_base) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // X[k*3] | Y[k*3] | w[k]
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // X[k*3] | Y[k*3] | w[k] | cdf[k] | scan scratch[256]
   add_device_offset(off_lo, off_hi, offp);
   float* sX = lds;
   float* sY = lds + (size_t)k * 3;
   float* sW = lds + (size_t)k * 6;
+  float* sC = lds + (size_t)k * 7;   // inclusive prefix sums of the weights (the on-device 3-sample draws through it)
+  float* sS = lds + (size_t)k * 8;
   const int r = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < k * 3; i += 256) {
@@ -608,6 +610,26 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
   }
   for (int i = threadIdx.x; i < k; i += 256) sW[i] = wts[(long long)r * k + i];
   __syncthreads();
+  const bool cdf_draw = !idx3_in && !noise3;
+  if (cdf_draw) {   // block scan: thread t owns the run [t * run, (t + 1) * run)
+    const int run = (k + 255) / 256, j0 = threadIdx.x * run;
+    float acc = 0.f;
+    for (int j = j0; j < min(k, j0 + run); ++j) acc += fmaxf(sW[j], 0.f);
+    sS[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {   // Hillis-Steele over the 256 run totals
+      const float v = threadIdx.x >= o ? sS[threadIdx.x - o] : 0.f;
+      __syncthreads();
+      sS[threadIdx.x] += v;
+      __syncthreads();
+    }
+    float c = threadIdx.x ? sS[threadIdx.x - 1] : 0.f;
+    for (int j = j0; j < min(k, j0 + run); ++j) {
+      c += fmaxf(sW[j], 0.f);
+      sC[j] = c;
+    }
+    __syncthreads();
+  }
   const int per = (it_ransac + nsplit - 1) / nsplit;
   const int h0 = part * per, h1 = min(it_ransac, h0 + per);
   const float beta = 5.0f / th_soft;
@@ -622,12 +644,56 @@ __global__ __launch_bounds__(256) void hypotheses_kernel(const float* __restrict
     double myH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float myam[3] = {0.f, 0.f, 0.f}, mybm[3] = {0.f, 0.f, 0.f};
     int mysel[3] = {0, 0, 0};
+    // On-device draws: lane i draws the triple of ITS hypothesis (hb + 4 i) by sequential sampling without replacement
+    // through the prefix sums -- the same (Plackett-Luce) distribution as the top-3 of the exponential race, order included,
+    // from 3 uniforms instead of k Exp(1) draws (the race over 2048 matches was two thirds of this kernel: 8 Philox calls,
+    // 32 logarithms and 32 divisions per lane and hypothesis).  Injected noise / indices keep the race (torch-comparable).
+    int draw3[3] = {0, 0, 0};
+    if (cdf_draw && lane < HYP_PASS && hb + 4 * lane < h1) {
+      const long long gh = (long long)r * it_ransac + hb + 4 * lane + set_base * it_ransac;   // GLOBAL hypothesis index
+      const U4 rnd = philox4x32(k0, k1, U4{0x3c6ef372u, (unsigned)gh, (unsigned)(gh >> 32) ^ off_hi ^ 0x5bd1e995u, off_lo});
+      const unsigned rr[3] = {rnd.x, rnd.y, rnd.z};
+      int ex[2] = {-1, -1};        // chosen so far, ascending
+      float exw[2] = {0.f, 0.f};   // their weights
+      float rem = sC[k - 1];
+      for (int d = 0; d < 3; ++d) {
+        const float u = ((float)(rr[d] >> 8) + 0.5f) * 5.9604644775390625e-8f;   // (0, 1) on a 2^-24 grid
+        const float target = u * rem;
+        // smallest j with F'(j) > target, F'(j) = cdf[j] - (weights of the chosen indices <= j)
+        int lo = 0, hi = k - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          float f = sC[mid];
+          if (ex[0] >= 0 && ex[0] <= mid) f -= exw[0];
+          if (ex[1] >= 0 && ex[1] <= mid) f -= exw[1];
+          if (f > target) hi = mid; else lo = mid + 1;
+        }
+        // round-off next to a chosen index / zero-weight runs: step to the next index that can be drawn; if nothing is
+        // left (fewer than three positive weights) the lowest index not yet chosen, as the race's tie rule does
+        int j = lo;
+        for (int tries = 0; tries < k && (j == ex[0] || j == ex[1] || !(sW[j] > 0.f)); ++tries) j = j + 1 < k ? j + 1 : 0;
+        if (j == ex[0] || j == ex[1] || !(sW[j] > 0.f)) {
+          j = 0;
+          while (j == ex[0] || j == ex[1]) ++j;
+        }
+        draw3[d] = j;
+        const float wj = fmaxf(sW[j], 0.f);
+        rem = fmaxf(rem - wj, 0.f);
+        if (ex[0] < 0) { ex[0] = j; exw[0] = wj; }
+        else if (j < ex[0]) { ex[1] = ex[0]; exw[1] = exw[0]; ex[0] = j; exw[0] = wj; }
+        else { ex[1] = j; exw[1] = wj; }
+      }
+    }
     for (int i = 0; i < HYP_PASS; ++i) {
       const int h = hb + 4 * i;
       if (h >= h1) break;
       const long long hyp = (long long)r * it_ransac + h;
       int sel[3];
-      if (idx3_in) {
+      if (cdf_draw) {
+        sel[0] = __shfl(draw3[0], i, 64);
+        sel[1] = __shfl(draw3[1], i, 64);
+        sel[2] = __shfl(draw3[2], i, 64);
+      } else if (idx3_in) {
         sel[0] = idx3_in[hyp * 3 + 0];
         sel[1] = idx3_in[hyp * 3 + 1];
         sel[2] = idx3_in[hyp * 3 + 2];
@@ -1129,9 +1195,9 @@ int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const
                          float* Rh, float* th, float* score, int* idx3, int nsets, int it_ransac, int k, long long set_base,
                          mk_stream_t stream) {
   MK_CHECK_ARG(X && Y && wts && Rh && th && score && idx3, "mk_ransac_hypotheses: null pointer");
-  MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 28 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 5485)");
+  MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 32 + 1024 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 4768)");
   const int nsplit = it_ransac >= 16 ? 4 : 1;
-  const size_t lds = (size_t)k * 7 * sizeof(float);
+  const size_t lds = ((size_t)k * 8 + 256) * sizeof(float);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)hypotheses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { mk_set_error("mk_ransac_hypotheses: cannot reserve %zu B of LDS", lds); return MK_ERR_LAUNCH; }

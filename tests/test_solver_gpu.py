@@ -330,3 +330,49 @@ def test_zero_pose_on_invalid_matrix(cfg):
             fs[1, 3, 3] = float("nan")
         sol = pipeline.solve(scfg, fs, d["kps0"], d["depth_kp0"], d["kps1"], d["depth_kp1"], d["K_color0"], d["K_color1"])
         assert float(sol["R"].abs().sum()) == 0 and float(sol["t"].abs().sum()) == 0 and float(sol["inliers"].abs().sum()) == 0
+
+
+def test_inner_three_sample_is_sequential_sampling_without_replacement():
+    """The on-device draw of a hypothesis' 3 correspondences (probabilisticProcrustes.py:251: torch.multinomial(weights, 3)):
+    sequential sampling through the prefix sums of the set's weights.  Against torch.multinomial on the same weights --
+    frequencies of the FIRST pick, of the SECOND pick and of inclusion, two-sample chi-square each (the top-3 of an exponential
+    race and sequential sampling without replacement are the same Plackett-Luce law, order included); never a repeated or a
+    zero-weight index; draws keyed by the global hypothesis index (set_base) and reproducible."""
+    import math
+    from mickey_amd import ops
+    dev = _dev()
+    k, nsets, it_r = 96, 600, 100
+    g = torch.Generator().manual_seed(5)
+    w = torch.rand((k,), generator=g) ** 5 + 1e-3          # heavy tail: pick probabilities from 4e-4 to 0.1
+    w[::9] = 0.0
+    X = torch.randn((nsets, k, 3), generator=g).to(dev)
+    Y = torch.randn((nsets, k, 3), generator=g).to(dev)
+    wd = w.to(dev)[None].repeat(nsets, 1).contiguous()
+    _, _, _, idx3 = ops.ransac_hypotheses(X, Y, wd, it_r, 0.3, seed=7, offset=4)
+    idx3 = idx3.long().cpu()
+    n = nsets * it_r
+    assert idx3.shape == (n, 3)
+    assert bool((idx3[:, 0] != idx3[:, 1]).all() and (idx3[:, 0] != idx3[:, 2]).all() and (idx3[:, 1] != idx3[:, 2]).all())
+    assert bool((w[idx3] > 0).all())
+    torch.manual_seed(2)
+    ref = torch.multinomial(w[None].expand(n, -1), 3, replacement=False)
+    for name, a, b in (("first", idx3[:, 0], ref[:, 0]), ("second", idx3[:, 1], ref[:, 1]), ("inclusion", idx3.reshape(-1), ref.reshape(-1))):
+        ca, cb = torch.bincount(a, minlength=k).double(), torch.bincount(b, minlength=k).double()
+        sel = (ca + cb) >= 20
+        df = int(sel.sum()) - 1
+        chi2 = float((((ca - cb) ** 2) / (ca + cb))[sel].sum())
+        assert abs(chi2 - df) < 5.0 * math.sqrt(2.0 * df), (name, chi2, df)
+    # reproducible; keyed by the global set index: sets [300, 600) drawn alone with set_base = 300 repeat their draws
+    _, _, _, again = ops.ransac_hypotheses(X, Y, wd, it_r, 0.3, seed=7, offset=4)
+    assert torch.equal(again.long().cpu(), idx3)
+    _, _, _, part = ops.ransac_hypotheses(X[300:].contiguous(), Y[300:].contiguous(), wd[300:].contiguous(), it_r, 0.3, seed=7, offset=4,
+                                          set_base=300)
+    assert torch.equal(part.long().cpu(), idx3[300 * it_r:])
+    _, _, _, other = ops.ransac_hypotheses(X, Y, wd, it_r, 0.3, seed=8, offset=4)
+    assert not torch.equal(other.long().cpu(), idx3)
+    # fewer than three positive weights: the remaining picks are the lowest free indices (the race's tie rule), never a repeat
+    w2 = torch.zeros((1, k), device=dev)
+    w2[0, 17] = 1.0
+    _, _, _, d3 = ops.ransac_hypotheses(X[:1].contiguous(), Y[:1].contiguous(), w2, 8, 0.3, seed=1, offset=0)
+    d3 = d3.long().cpu()
+    assert bool((d3[:, 0] == 17).all()) and bool((d3[:, 1] == 0).all()) and bool((d3[:, 2] == 1).all())
