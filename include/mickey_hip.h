@@ -145,6 +145,13 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                  float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
                  int bord_w, int bord_m, int dtype, mk_stream_t stream);
 
+/* The same LayerNorm writing its rows as the (hi, lo) fp16 operand planes of the split-operand head kernels (mk_conv3x3_split,
+ * mk_gemm_grouped_split; AMD.HEADS_DTYPE: split): LN(x) * plane_scale = hi + lo, both [.., ldo] fp16, dense or bordered as above
+ * (no fp32 copy, no separate mk_split_planes pass). */
+int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
+                        float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
+                        int bord_h, int bord_w, int bord_m, mk_stream_t stream);
+
 /* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
  * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
  * out lp [nimg*ntok, ldo] with column head*64 + d. */

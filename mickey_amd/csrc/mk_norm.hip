@@ -10,6 +10,20 @@
 namespace {
 using namespace mk;
 
+// out_is_f32 == 2: the row goes out as the (hi, lo) fp16 operand planes of the split-operand head kernels
+// (mk_conv3x3_split / mk_gemm_grouped_split): y * scale = hi + lo, saturating at fp16's largest finite value
+__device__ __forceinline__ void store_planes(void* hi, void* lo, long long o, const f32x4& y, float scale) {
+  f16x4 oh, ol;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float sv = fminf(fmaxf(y[e] * scale, -65504.f), 65504.f);
+    oh[e] = (_Float16)sv;
+    ol[e] = (_Float16)(sv - (float)oh[e]);
+  }
+  *(f16x4*)((_Float16*)hi + o) = oh;
+  *(f16x4*)((_Float16*)lo + o) = ol;
+}
+
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048 (instantiated for 4 as well: D <= 1024 needs half the registers)
 
 constexpr int LN_RPW = 4;   // rows per wave: the loads of row r+1 are in flight while row r is reduced and stored
@@ -20,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
                                                         int rows_per_img, int skip, int wgroup_rows, int bord_h, int bord_w,
-                                                        int bord_m) {
+                                                        int bord_m, void* out_lo, float plane_scale) {
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
   if (r0 >= rows_out) return;
@@ -102,7 +116,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           *(f32x4*)rp = y;
         }
         if (out) {
-          if (out_is_f32) {
+          if (out_is_f32 == 2) {
+            store_planes(out, out_lo, ro * ldo + c, y, plane_scale);
+          } else if (out_is_f32) {
             *(f32x4*)((float*)out + ro * ldo + c) = y;
           } else {
             typename Lp<T>::V4 o;
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
                                                                const float* __restrict__ b, float eps, void* out, int ldo,
                                                                int out_is_f32, float* resid, int ldr, int rows_out, int D,
                                                                int rows_per_img, int skip, int wgroup_rows, int bord_h,
-                                                               int bord_w, int bord_m) {
+                                                               int bord_w, int bord_m, void* out_lo, float plane_scale) {
   const int lane = threadIdx.x & 63, half = lane >> 5, c = (lane & 31) * 4;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * LNN_TRIPS);
   if (r0 >= rows_out) return;
@@ -172,7 +188,9 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
         const int gb = r / bord_m, m = r - gb * bord_m;
         ro = gb * bordered_rows(bord_m / (bord_h * bord_w), bord_h, bord_w) + bordered_row(m, bord_h, bord_w);
       }
-      if (out_is_f32) {
+      if (out_is_f32 == 2) {
+        store_planes(out, out_lo, ro * ldo + c, y, plane_scale);
+      } else if (out_is_f32) {
         *(f32x4*)((float*)out + ro * ldo + c) = y;
       } else {
         typename Lp<T>::V4 o;
@@ -303,9 +321,9 @@ extern "C" {
 int mk_version(void) { return 100; }
 const char* mk_last_error(void) { return g_err; }
 
-int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
-                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
-                 int bord_w, int bord_m, int dtype, mk_stream_t stream) {
+static int layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
+                            float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
+                            int bord_w, int bord_m, int dtype, void* out_lo, float plane_scale, mk_stream_t stream) {
   MK_CHECK_ARG(x && w && b && (out || resid), "mk_layernorm: null pointer");
   MK_CHECK_ARG(bord_h == 0 || (bord_h > 0 && bord_w > 0 && bord_m > 0 && bord_m % (bord_h * bord_w) == 0 && rows_out % bord_m == 0),
                "mk_layernorm: bordered output needs rows_out = k * bord_m, bord_m = nimg * bord_h * bord_w");
@@ -317,7 +335,7 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
     dim3 gridn((rows_out + 8 * LNN_TRIPS - 1) / (8 * LNN_TRIPS));
 #define MK_LNN(T_)                                                                                                         \
   hipLaunchKernelGGL((layernorm_narrow_kernel<T_>), gridn, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale)
     if (dtype == MK_BF16) MK_LNN(__bf16);
     else if (dtype == MK_F16) MK_LNN(_Float16);
     else MK_LNN(float);
@@ -328,7 +346,7 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
 #define MK_LN(T_, V_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale)
   if (dtype == MK_BF16) {
     if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
   } else if (dtype == MK_F16) {
@@ -339,6 +357,21 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
 #undef MK_LN
   MK_CHECK_LAUNCH();
   return MK_OK;
+}
+
+int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
+                 float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
+                 int bord_w, int bord_m, int dtype, mk_stream_t stream) {
+  return layernorm_launch(x, ldx, w, b, eps, out, ldo, out_is_f32 ? 1 : 0, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows,
+                          bord_h, bord_w, bord_m, dtype, nullptr, 1.0f, stream);
+}
+
+int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
+                        float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
+                        int bord_h, int bord_w, int bord_m, mk_stream_t stream) {
+  MK_CHECK_ARG(out_hi && out_lo, "mk_layernorm_planes: null plane pointer");
+  return layernorm_launch(x, ldx, w, b, eps, out_hi, ldo, 2, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w,
+                          bord_m, MK_F32, out_lo, plane_scale, stream);
 }
 
 int mk_im2col_patch14(const float* img, long long stride_img, long long stride_ch, int stride_row, int nimg, int gh,

@@ -146,6 +146,15 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
         rows_per_img = rows_in
     if rows_out is None:
         rows_out = rows_in - skip * (rows_in // rows_per_img)
+    if isinstance(out, (tuple, list)):   # (hi, lo) fp16 planes: the operand form of the split-operand head kernels
+        oh, ol = out
+        assert oh.dtype == torch.float16 and ol.dtype == torch.float16 and oh.stride() == ol.stride()
+        ldo = oh.stride(-2) if ldo is None else ldo
+        bh, bw, bm = (bordered[1], bordered[2], bordered[0] * bordered[1] * bordered[2]) if bordered else (0, 0, 0)
+        call("mk_layernorm_planes", ptr(x), x.stride(-2) if ldx is None else ldx, ptr(w), ptr(b), float(eps), ptr(oh), ptr(ol), ldo,
+             SPLIT_ACT_SCALE, ptr(resid), (resid.stride(-2) if resid is not None else D) if ldr is None else ldr, rows_out, D,
+             rows_per_img, skip, wgroup_rows, bh, bw, bm, stream())
+        return out
     if out is None and out_dtype is not None:
         out = torch.empty((rows_out, D), device=x.device, dtype=out_dtype)
     is_f32 = out is not None and out.dtype == torch.float32

@@ -91,17 +91,24 @@ def encoder_forward(W, ws, img):
     # the heads' operand type, as a BORDERED feature map (mickey_hip.h: what a 3x3 conv reads; border rows stay zero)
     # (bordered buffers are zeroed ONCE and only their pixel rows are ever written: the key carries the geometry, because two
     # geometries can share a row count while their border rows sit elsewhere)
-    feat = ws.get("feat_%d_%d_%d" % (nimg, gh, gw), (ops.bordered_rows(nimg, gh, gw), D), getattr(W, "lp_heads", lp), dev, zero=True)
+    R = ops.bordered_rows(nimg, gh, gw)
+    if getattr(W, "heads_split", False):
+        # split-operand heads: the final norm writes the convs' (hi, lo) fp16 operand planes directly (no fp32 feature map)
+        feat = (ws.get("feat_hi_%d_%d_%d" % (nimg, gh, gw), (R, D), torch.float16, dev, zero=True),
+                ws.get("feat_lo_%d_%d_%d" % (nimg, gh, gw), (R, D), torch.float16, dev, zero=True))
+    else:
+        feat = ws.get("feat_%d_%d_%d" % (nimg, gh, gw), (R, D), getattr(W, "lp_heads", lp), dev, zero=True)
     ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
                   bordered=(nimg, gh, gw))
     return feat, gh, gw
 
 
 def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
-    """feat lp, bordered feature map of nimg gh x gw grids [bordered_rows, D] -> scr [nimg,1,n], kps [nimg,2,n]
+    """feat lp, bordered feature map of nimg gh x gw grids [bordered_rows, D] (split-operand heads: its (hi, lo) fp16 planes)
+    -> scr [nimg,1,n], kps [nimg,2,n]
     (absolute pixels), depth [nimg,1,n], dsc [nimg,Cd,n], all fp32.  Every activation a 3x3 conv reads is bordered (zeroed
     once at allocation, the kernels write pixels only); what only row-wise kernels read is dense."""
-    dev, lp = feat.device, getattr(W, "lp_heads", W.lp)
+    dev, lp = (feat[0] if isinstance(feat, tuple) else feat).device, getattr(W, "lp_heads", W.lp)
     n = gh * gw
     M = nimg * n
     G = 4
@@ -113,19 +120,12 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     def wsc(w):   # power-of-two scale of a split weight tensor's planes (weights.prepare)
         return W.wscale[w.data_ptr()]
 
-    def planes(name, x):
-        """fp32 (bordered) activation -> its (hi, lo) fp16 planes, the operand form of mk_conv3x3_split; border rows are
-        zeros in x, hence in both planes."""
-        hi = ws.get(name + "_hi" + geo, tuple(x.shape), torch.float16, dev)
-        lo = ws.get(name + "_lo" + geo, tuple(x.shape), torch.float16, dev)
-        return ops.split_planes(x, hi, lo)
-
     def plane_pair(name, shape):
         """Zeroed (hi, lo) fp16 planes of a bordered activation that a split conv WRITES (the next split conv's operands)."""
         return (ws.get(name + "_hi" + geo, shape, torch.float16, dev, zero=True), ws.get(name + "_lo" + geo, shape, torch.float16, dev, zero=True))
 
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
-    xp = planes("feat", feat) if split else None
+    xp = feat if split else None   # (the final norm wrote the planes)
     for bi, rb in enumerate(W.rb):
         co = rb.cout
         last = bi == len(W.rb) - 1   # its output feeds the attention layers (row-wise kernels): dense rows
@@ -167,7 +167,11 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     msg = ws.get("att_msg", (G, M, C), lp, dev)
     mrg = ws.get("att_mrg", (G, M, C), torch.float32, dev)
     hid = ws.get("att_hid", (G, M, 2 * C), lp, dev)
-    x4 = ws.get("att_out" + geo, (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
+    if split:
+        x4 = None
+        x4h, x4l = plane_pair("att_out", (G, R, C))   # read by resblock4's convs: bordered planes, written by the last LayerNorm
+    else:
+        x4 = ws.get("att_out" + geo, (G, R, C), lp, dev, zero=True)   # read by resblock4's convs: bordered
     nl = len(W.att)
     if split:
         # the layers' small linears on split operands too (fp32 MFMA: 4.9 ms per 32 pairs; split: the conversions below + 12
@@ -179,16 +183,16 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     for li, lay in enumerate(W.att):
         last = li == nl - 1
         if split:
-            ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C])
+            if li == 0:   # later layers: the previous layer's closing LayerNorm wrote these planes
+                ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C])
             ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 3 * C, 0, M * 3 * C,
                                    w_scale=wsc(lay.qkv_w))
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
             ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
             ops.split_planes(msg, msgp[0], msgp[1])
             ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 3 * C, 0, M * C, w_scale=wsc(lay.merge_w))
-            ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
-                          wgroup_rows=M)
-            ops.split_planes(cat[:, :, C:], catp[0][:, :, C:], catp[1][:, :, C:])
+            ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=(catp[0][:, :, C:], catp[1][:, :, C:]), ldo=2 * C, rows_out=G * M,
+                          rows_per_img=G * M, wgroup_rows=M)
             ops.gemm_grouped_split(catp, lay.mlp0_w, None, hidp, G, M, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 2 * C * 3 * 2 * C, 0,
                                    M * 2 * C, act=ops.ACT_RELU, w_scale=wsc(lay.mlp0_w))
             ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 3 * 2 * C, 0, M * C,
@@ -203,7 +207,11 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
             ops.gemm_grouped(cat, lay.mlp0_w, None, hid, G, M, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 4 * C * C, 0,
                              M * 2 * C, act=ops.ACT_RELU)
             ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
-        ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=x4 if last else cat, ldo=C if last else 2 * C, resid=xs,
+        if split:   # the layer's output as operand planes: of the next layer's `cat`, or (last) of resblock4's bordered input
+            o2 = (x4h, x4l) if last else (catp[0][:, :, :C], catp[1][:, :, :C])
+        else:
+            o2 = x4 if last else cat
+        ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=o2, ldo=C if last else 2 * C, resid=xs,
                       rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None)
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
@@ -212,7 +220,6 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     cd = dw.cout
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
     if split:
-        x4h, x4l = planes("att_out", x4)
         h4p = plane_pair("rb4_h", (3, R, ck))
         ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C, w_scale=wsc(kpw.w1),
                           stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
