@@ -165,7 +165,7 @@ class StageProfiler:
         def ln_bytes(x, w, b, eps, out=None, out_dtype=None, resid=None, rows_out=None, **k):
             D = w.shape[-1]
             rows = rows_out if rows_out is not None else x.numel() // x.shape[-1]
-            ob = esz(out) if out is not None else 2
+            ob = 4 if isinstance(out, (tuple, list)) else (esz(out) if out is not None else 2)   # (hi, lo) fp16 planes: 2 + 2 bytes
             return rows * D * (4 + ob + (4 if resid is not None else 0))
         timed("layernorm", "layernorm", ln_bytes)
 

@@ -1,8 +1,5 @@
 #!/bin/bash
-# round 4, GPU call H: hypotheses kernel with the CDF 3-sample, LayerNorms writing operand planes (split heads), sampler tweaks
 mkdir -p gpurun_out
-timeout 900 python -m pytest -q -m gpu -rf tests/test_solver_gpu.py tests/test_train_ransac_gpu.py 2>&1 | tail -5 | tee gpurun_out/r04h_pytest_solver.txt
-timeout 1200 python -m pytest -q -m gpu -rf -s tests/test_model_gpu.py tests/test_bench_config_gpu.py tests/test_kernels_gpu.py -k "split or invariance or graph or determinism or layernorm or sampler" 2>&1 | grep -v "^$" | tail -22 | tee gpurun_out/r04h_pytest_model.txt
 timeout 900 python bench.py --steps 10 --warmup 3 --legs fp16,ref_split --no-sustained --no-cpu-baseline --no-h2d 2>gpurun_out/r04h_bench.err | tail -1 > gpurun_out/r04h_bench_b32.json
 python - <<'PY'
 import json
