@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence for the build that is benchmarked (run on the GPU box through gpurun):
-#   1. the default bench line                                   -> gpurun_out/${TAG}_bench_b32.json
+#   1. (last, once the traffic file exists) the default bench line -> gpurun_out/${TAG}_bench_b32.json
 #   2. rocprofv3 --kernel-trace --stats of bench.py --steps 5   -> gpurun_out/${TAG}_bench_b32_kernel_stats.csv (+ the line under rocprof)
 #   3. PMC passes of the same workload, one counter group per pass (TCC: FETCH_SIZE costs 3 of 4 slots, WRITE_SIZE 2;
 #      never combined with other trace domains), post-processed per kernel ROLE -> gpurun_out/${TAG}_pmc_traffic.json
@@ -13,9 +13,6 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
-if [ -z "$SKIP_BENCH" ]; then
-  timeout 900 python bench.py --steps $STEPS_BENCH --warmup 3 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
-fi
 cd /tmp
 rm -rf /tmp/prof_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $R/bench.py --steps 5 --warmup 2 --lean > /tmp/prof_$TAG.log 2>&1
@@ -98,4 +95,11 @@ for k, d in sorted(b.items()):
 json.dump(busy, open("%s/gpurun_out/%s_pmc_busy.json" % (R, TAG), "w"), indent=1)
 print(json.dumps({"traffic_roles": {k: v for k, v in roles.items() if "gemm" in k or "attention" in k}, "busy": busy["roles"]}, indent=1)[:3000])
 PY
+# the bench line LAST, with the traffic file of this very build in place (bench.py reads profiles/${TAG}_pmc_traffic.json when the
+# source hash matches), so that the line carries roofline.traffic and the per-stage traffic
+cd $R
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+if [ -z "$SKIP_BENCH" ]; then
+  timeout 900 python bench.py --steps $STEPS_BENCH --warmup 3 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
+fi
 head -c 900 $R/gpurun_out/${TAG}_bench_b32.json; echo; head -6 $R/gpurun_out/${TAG}_bench_b32_kernel_stats.csv | cut -c1-200
