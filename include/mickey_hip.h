@@ -295,7 +295,10 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  * r in [0, rows_per_pair): idx[b*rows_per_pair + r, 0..k) = indices of the k largest p[b, c] / e[b, r, c],
  * in descending key order (the order torch.topk returns).
  *   p      [B, ncell] fp32, >= 0
- *   noise  NULL: e drawn on device from Philox4x32-10(seed, offset); else fp32 [B*rows_per_pair, ncell]
+ *   noise  NULL: the race is drawn on device from Philox4x32-10(seed, offset) -- not cell by cell: with the threshold T of the
+ *          keys known from the histogram of p, the candidates {p / e > T} of a row are generated directly as a thinned
+ *          Bernoulli process (geometric skipping under a per-16-cell bound of p, acceptance s / S, e drawn from Exp(1)
+ *          conditioned on e < p / T; mk_solver.hip), the same law as drawing every e; else fp32 [B*rows_per_pair, ncell]
  *          injected Exp(1) draws (tests: bit-comparable with torch)
  *   idx    int32 [B*rows_per_pair, k];  cnt int32 [B*rows_per_pair] = number of non-zero-key entries
  *          actually available (< k only if fewer than k cells have p > 0; the tail is then filled
@@ -303,11 +306,11 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  *   invalid int32 [1] or NULL: OR-ed with 1 when torch.multinomial would have raised (a NaN / inf /
  *          negative probability, or a row without any positive cell) -- the reference then returns
  *          the zero pose for the whole batch (probabilisticProcrustes.py:331-336)
- *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k), 16-byte aligned
+ *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k, ncell), 16-byte aligned
  *   pair_base  GLOBAL index of pair 0 of this call.  The Philox streams are keyed by (seed, offset, global pair index,
  *          draw, cell), so a batch may be split arbitrarily -- over calls or over the GPUs of a node -- without changing
  *          any pair's draws: pair i of a B = 32 call and the same pair alone with pair_base = i sample identically. */
-long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k);
+long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k, long long ncell);
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
                     const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
                     long long ncell, int k, int pair_base, mk_stream_t stream);

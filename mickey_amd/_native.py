@@ -54,7 +54,7 @@ SIGNATURES = {
     "mk_sinkhorn_work_floats": ("l", "iii"),
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),
-    "mk_exprace_topk_work_bytes": ("l", "iii"),
+    "mk_exprace_topk_work_bytes": ("l", "iiil"),
     "mk_exprace_topk": ("i", "ppuupppppiiliip"),
     "mk_counter_add": ("i", "pup"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),
@@ -74,6 +74,7 @@ DEV_SIGNATURES = {
     "mk_attn_set_mode": ("i", "i"),
     "mk_sinkhorn_set_group": ("i", "i"),
     "mk_dual_softmax_set_chunks": ("i", "i"),
+    "mk_exprace_set_mode": ("i", "i"),
 }
 
 _lib = None

@@ -126,7 +126,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
 }
 
 int g_num_cus = 0;
-int g_band_m = 8;      // m-tiles per band of the 256x256 tile order (dev: mk_gemm_set_tile 400 + b)
+int g_band_m = 0;      // tile order of the 256x256 kernels: 0 automatic, b > 0 bands of b m-tiles, -g groups of g n-tiles (dev: mk_gemm_set_tile 400 + b / 464 + g)
 int g_half_rows = 1;   // automatic choice may use the 64x128 tiling for under-filled launches (dev: 500 off / 501 on)
 int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong
 
@@ -191,7 +191,11 @@ extern "C" {
 
 int mk_gemm_set_tile(int mode) {
   if (mode >= 400 && mode < 464) {   // dev: band height of the 256x256 tile order
-    g_band_m = mode - 400 > 0 ? mode - 400 : 1;
+    g_band_m = mode - 400;   // 400: automatic
+    return MK_OK;
+  }
+  if (mode >= 464 && mode < 496) {   // dev: n-group tile order (groups of mode - 464 n-tiles walked m-major); 464: automatic
+    g_band_m = -(mode - 464);
     return MK_OK;
   }
   if (mode == 500 || mode == 501) {   // dev: automatic use of the 64x128 tiling off / on

@@ -951,9 +951,22 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8
   }
 }
 
-// Tile order of the 256x256 kernels: bands of PP_GM m-tiles walked n-major (on top of the XCD remap), so the 32 tiles an
-// XCD works on at one time form an 8 x 4 block of the output (A and W panels shared in its L2).
+// Tile order of the 256x256 kernels (on top of the XCD remap: an XCD walks a contiguous range of ids, 32 at a time).
+//   PP_GM > 0  bands of PP_GM m-tiles walked n-major: the 32 tiles in flight form an 8 x 4 block of the output; the band's A
+//              panels are fetched once per 4 n-tiles, the 4 W panels once per 32 tiles;
+//   PP_GM < 0  groups of -PP_GM n-tiles walked m-major (n fastest): the group's W panels (-PP_GM x 256 x K) stay in the XCD's
+//              L2 for the whole walk down M, every A panel is fetched once per GROUP -- less L2-miss traffic when N is several
+//              groups wide and a group's W fits the 4-MB L2 (qkv, fc1: K = 1024, 512 KB per n-tile).
 __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_GM, int& tm, int& tn) {
+  if (PP_GM < 0) {
+    const int ng = -PP_GM;
+    const int grp = id / (ntm * ng);
+    const int rem = id - grp * (ntm * ng);
+    const int gn = min(ng, ntn - grp * ng);
+    tm = rem / gn;
+    tn = grp * ng + rem - tm * gn;
+    return;
+  }
   const int band = id / (PP_GM * ntn);
   const int rem = id - band * (PP_GM * ntn);
   const int gm = min(PP_GM, ntm - band * PP_GM);

@@ -250,6 +250,11 @@ int launch_k(const GemmParams& p, int groups, hipStream_t st, int band_m) {
     attr_done = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  // tile order (pp_tile_coords): outputs at most 4 tiles wide (proj, fc2: N = 1024) are walked m-major with n fastest -- the
+  // 32 tiles in flight are the same 8 x 4 block as in a band, but neighbouring CUs share the (large) A panel: -19 % L2-miss
+  // traffic and +2.6 % on fc2 (profiles/r04j_gemm_order.txt); wider outputs keep bands of 8 m-tiles (n-groups there cut the
+  // traffic as much and cost 1-6 % of time)
+  if (band_m == 0) band_m = (AMODE == A_DENSE && ntn <= 4) ? -4 : 8;
   hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND>), dim3(ntm * ntn, groups, 1), dim3(512), LDS, st, p, band_m);
   MK_CHECK_LAUNCH();
   return MK_OK;

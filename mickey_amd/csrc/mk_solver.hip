@@ -79,6 +79,8 @@ struct TopkWork {
   unsigned long long* cand;  // [R][CAND_MAX]
   int* invalid;              // [1] or null
   int pair_base;             // global index of pair 0 of this call (keys the Philox streams)
+  float* pmax;               // [B][nblk]    largest valid p of every 16 consecutive cells (bound of the skip sampler)
+  long long nblk;            // ceil(ncell / 16)
 };
 
 __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsigned k0, unsigned k1, unsigned off_lo,
@@ -303,6 +305,200 @@ __global__ __launch_bounds__(256) void exprace_prefilter_kernel(const float* __r
   }
 }
 
+// ---- Philox collect pass by geometric skipping (the product path) ------------------------------------------------------------
+// With the analytic threshold T a (row, cell) becomes a candidate iff its Exp(1) draw e < p / T: independent Bernoulli events
+// of probability s = 1 - exp(-p / T), ~7e-4 on average (1.25 k candidates per row out of n^2 cells).  Testing every (row, cell)
+// costs a Philox call per cell even with the pre-filter above; here the candidates of a row are generated DIRECTLY, as a thinned
+// Bernoulli process:
+//   bound     pmax = largest p of every 16 consecutive cells (written by the histogram pass): every cell of the block is
+//             "proposed" with probability S = 1 - exp(-lam), lam = pmax / T >= p / T;
+//   walk      proposals are found by skipping: an Exp(1) budget x is spent at the rate lam per cell, the next proposal is cell
+//             floor(x / lam) of the block, or -- memorylessness -- the rest of the budget carries over to the thread's next
+//             block (two Philox calls per thread for 5 rows x 16 blocks, not one per cell); after a proposal the process
+//             resumes at the next cell with a fresh budget;
+//   thinning  a proposed cell is accepted with probability s / S (second uniform, keyed by (cell, row)), so it survives with
+//             probability s exactly; its race key is p / e with e drawn from Exp(1) conditioned on e < p / T:
+//             e = -log1p(-u s);
+//   dense     blocks with lam > 0.1 (around a dominant cell; everything when T = 0) skip the skipping: their 16 cells are
+//             tested directly with probability s.
+// Proposals are queued in LDS and tested densely (all lanes busy), candidates are appended as in the passes above, and the
+// select kernel sorts them: the result is the top-k of the race keys of a row -- the same sampling law, with the RNG work
+// proportional to the number of candidates instead of the number of cells.  The walk geometry depends on ncell only (not on
+// the batch), so a pair's draws do not depend on the batch it is in.
+// Counter layout: x = walk thread (+ call << 26) | cell, z = (pair + pair_base) * 512 + {288 + row group (walk) | row (test)}.
+constexpr int SK_CELLS = 16;                 // cells per bound block
+constexpr int SK_NBW = 16;                   // blocks per thread (their rates live in registers for all rows of the workgroup)
+constexpr int SK_RANGE = 256 * SK_NBW;       // blocks per workgroup (65536 cells: a queue entry holds the local cell in 16 bits)
+constexpr int SK_ROWS = 5;                   // rows per workgroup
+constexpr int SK_QCAP = 1024;                // queued proposals (expected ~300)
+constexpr int SK_DCAP = 2048;                // queued dense (block, row) entries
+constexpr int SK_LCAP = 128;                 // LDS candidate slots per row and workgroup (expected ~45); beyond: appended directly
+constexpr int SK_HSLOTS = 4;                 // LDS slots of a thread for its hits (expected 0.9 per thread)
+constexpr float SK_DENSE = 0.1f;
+// A queue that overflows (a workgroup range with thousands of proposals: not a distribution a matcher produces) raises
+// `redo`: the exact histogram passes then redo the whole call from scratch.
+
+__global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restrict__ p, unsigned k0, unsigned k1, unsigned off_lo,
+                                                           unsigned off_hi, const unsigned long long* __restrict__ offp,
+                                                           TopkWork w, int rows_per_pair, long long ncell) {
+  __shared__ unsigned long long lbuf[SK_ROWS * SK_LCAP], hits[SK_QCAP], slots[SK_HSLOTS * 256];
+  __shared__ unsigned dqueue[SK_DCAP];
+  __shared__ unsigned lcount[SK_ROWS], lbase[SK_ROWS], qcount, dcount;
+  add_device_offset(off_lo, off_hi, offp);
+  const int b = blockIdx.z, r0 = blockIdx.y * SK_ROWS, nr = min(SK_ROWS, rows_per_pair - r0), t = threadIdx.x;
+  const long long blk0 = (long long)blockIdx.x * SK_RANGE;
+  const int nb = (int)min((long long)SK_RANGE, w.nblk - blk0);
+  const long long cbase = blk0 * SK_CELLS;
+  const unsigned zb = (unsigned)(b + w.pair_base) * 512u;
+  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (exprace_athresh_kernel)
+  const float T = __uint_as_float((unsigned)thr0 << 20);
+  const float invT = T > 0.f ? 1.f / T : __builtin_inff();   // T = 0: "collect every positive cell"
+  const float* pb = p + (long long)b * ncell;
+  const float* pmb = w.pmax + (long long)b * w.nblk + blk0;
+  // budget a block takes off the walk: 16 x its rate bound (block j * 256 + t of the range); +inf marks a dense block
+  float span[SK_NBW];
+#pragma unroll
+  for (int j = 0; j < SK_NBW; ++j) {
+    const int bl = j * 256 + t;
+    const float pm = bl < nb ? pmb[bl] : 0.f;
+    const float lj = pm > 0.f ? pm * invT : 0.f;
+    span[j] = lj > SK_DENSE ? __builtin_inff() : (float)SK_CELLS * lj;
+  }
+  if (t < SK_ROWS) lcount[t] = 0;
+  if (t == 0) { qcount = 0; dcount = 0; }
+  __syncthreads();
+
+  // ---- the walk.  It only FINDS the blocks with a proposal: a hit (block, row, budget left at the block) goes to the
+  // thread's own LDS slots (no return value to wait for) and the walk goes on at the next block with a fresh budget
+  // (memorylessness again); the rest of the hit block belongs to phase 2.  A wave step covers 1024 cells and half of the
+  // steps have a hit in some lane, so whatever a hit costs is paid by all 64 lanes: no LDS round trip, no RNG call and no
+  // logarithm inside the loop in the common case.
+  // Budgets: hardware log2 (1 ulp-class; they only place the proposals).  Two Philox calls per thread hold the first budget of
+  // each of the workgroup's rows and three spares; a thread with more hits draws again.
+  auto budget_of = [](unsigned r) { return -0.69314718055994531f * __builtin_amdgcn_logf(((float)(r >> 8) + 0.5f) * 5.9604644775390625e-8f); };
+  const unsigned walk = blockIdx.x * 256u + (unsigned)t, zw = zb + 288u + blockIdx.y;
+  const U4 ra = philox4x32(k0, k1, U4{walk, off_hi, zw, off_lo});
+  const U4 rb = philox4x32(k0, k1, U4{walk | (1u << 26), off_hi, zw, off_lo});
+  const float first[SK_ROWS] = {budget_of(ra.x), budget_of(ra.y), budget_of(ra.z), budget_of(ra.w), budget_of(rb.x)};
+  float sp0 = budget_of(rb.y), sp1 = budget_of(rb.z), sp2 = budget_of(rb.w), sp3 = 0.f;   // spare budgets, used from sp0 up
+  int left = 3;          // spares left
+  unsigned refill = 1;
+  bool over = false;
+  int nh = 0;
+  static_assert(SK_ROWS == 5, "first budgets: ra.x .. ra.w, rb.x");
+#pragma unroll 1
+  for (int rl = 0; rl < nr; ++rl) {
+    float budget = rl == 0 ? first[0] : rl == 1 ? first[1] : rl == 2 ? first[2] : rl == 3 ? first[3] : first[4];
+#pragma unroll
+    for (int j = 0; j < SK_NBW; ++j) {
+      if (!(budget < span[j])) {   // (the common case, also every empty block: no proposal)
+        budget -= span[j];
+        continue;
+      }
+      const unsigned meta = (unsigned)(j * 256 + t) | ((unsigned)rl << 16);
+      if (span[j] == __builtin_inff()) {   // dense: spends no budget (it is not part of the skipping process)
+        const unsigned pos = atomicAdd(&dcount, 1u);
+        if (pos < (unsigned)SK_DCAP) dqueue[pos] = meta;
+        else over = true;
+        continue;
+      }
+      const unsigned long long e = ((unsigned long long)meta << 32) | __float_as_uint(budget);
+      if (nh < SK_HSLOTS) {
+        slots[nh * 256 + t] = e;
+      } else {   // more hits than slots in one thread: straight to the queue
+        const unsigned pos = atomicAdd(&qcount, 1u);
+        if (pos < (unsigned)SK_QCAP) hits[pos] = e;
+        else over = true;
+      }
+      ++nh;
+      if (left == 0) {   // the spares are spent: next call of this walk
+        ++refill;
+        const U4 rc = philox4x32(k0, k1, U4{walk | (refill << 26), off_hi, zw, off_lo});
+        sp0 = budget_of(rc.x); sp1 = budget_of(rc.y); sp2 = budget_of(rc.z); sp3 = budget_of(rc.w);
+        left = 4;
+        budget = sp0; sp0 = sp1; sp1 = sp2; sp2 = sp3;
+      } else {
+        budget = sp0; sp0 = sp1; sp1 = sp2; sp2 = sp3;
+      }
+      --left;
+    }
+  }
+  const int nown = min(nh, SK_HSLOTS);
+  if (nown) {
+    const unsigned base = atomicAdd(&qcount, (unsigned)nown);
+    if (base + nown > (unsigned)SK_QCAP) over = true;
+#pragma unroll
+    for (int h = 0; h < SK_HSLOTS; ++h)
+      if (h < nown && base + h < (unsigned)SK_QCAP) hits[base + h] = slots[h * 256 + t];
+  }
+  if (over) atomicOr(w.redo, 1);
+  __syncthreads();
+
+  // thinning + conditional race key of one proposed (cell, row); rnd = Philox keyed by (cell, row)
+  auto test = [&](long long c, int rl, float bound, const U4& rnd) {
+    if (c >= ncell) return;
+    const float pv = pb[c];
+    if (!(pv > 0.f) || isinf(pv)) return;
+    const float s = -expm1f(-pv * invT);
+    const float ua = ((float)(rnd.x >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    if (!(ua * bound < s)) return;
+    const float uk = ((float)(rnd.y >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float e = -log1pf(-uk * s);
+    if (!(e > 0.f)) return;
+    const unsigned bits = __float_as_uint(pv / e);
+    const unsigned long long item = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
+    const unsigned ls = atomicAdd(&lcount[rl], 1u);
+    if (ls < (unsigned)SK_LCAP) {
+      lbuf[rl * SK_LCAP + ls] = item;
+    } else {
+      const int row = b * rows_per_pair + r0 + rl;
+      const unsigned slot = atomicAdd(&w.ncand[row], 1u);
+      if (slot < CAND_MAX) w.cand[(long long)row * CAND_MAX + slot] = item;
+    }
+  };
+  // ---- phase 2a: one lane per hit block.  The first proposal sits where the walk's budget ran out; after every proposal the
+  // rest of the block is walked with a fresh budget (third word of the cell's Philox call).
+  const unsigned nq = min(qcount, (unsigned)SK_QCAP), nd = min(dcount, (unsigned)SK_DCAP);
+  for (unsigned i = t; i < nq; i += 256) {
+    const unsigned long long e = hits[i];
+    const unsigned meta = (unsigned)(e >> 32);
+    const int bl = (int)(meta & 0xffffu), rl = (int)(meta >> 16);
+    const float lj = pmb[bl] * invT;
+    const float bound = -expm1f(-lj);
+    float budget = __uint_as_float((unsigned)e), left = (float)SK_CELLS;
+#pragma unroll 1
+    while (true) {
+      const int cell = SK_CELLS - (int)left + min((int)(budget / lj), (int)left - 1);
+      const long long c = cbase + (long long)bl * SK_CELLS + cell;
+      const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, off_hi, zb + (unsigned)(r0 + rl), off_lo});
+      test(c, rl, bound, rnd);
+      left = (float)(SK_CELLS - 1 - cell);
+      budget = budget_of(rnd.z);
+      if (!(budget < left * lj)) break;
+    }
+  }
+  // ---- phase 2b: the 16 cells of every dense (block, row) entry, one lane each, accepted with probability s
+  for (unsigned i = t; i < nd * SK_CELLS; i += 256) {
+    const unsigned meta = dqueue[i / SK_CELLS];
+    const long long c = cbase + (long long)(meta & 0xffffu) * SK_CELLS + (i % SK_CELLS);
+    const int rl = (int)(meta >> 16);
+    const U4 rnd = philox4x32(k0, k1, U4{(unsigned)c, off_hi, zb + (unsigned)(r0 + rl), off_lo});
+    test(c, rl, 1.f, rnd);
+  }
+  __syncthreads();
+  if (t < nr) {
+    const unsigned nloc = min(lcount[t], (unsigned)SK_LCAP);
+    lbase[t] = nloc ? atomicAdd(&w.ncand[b * rows_per_pair + r0 + t], nloc) : 0u;
+  }
+  __syncthreads();
+  for (int rl = 0; rl < nr; ++rl) {
+    const unsigned nloc = min(lcount[rl], (unsigned)SK_LCAP), bs = lbase[rl];
+    const long long row = (long long)b * rows_per_pair + r0 + rl;
+    for (unsigned i = t; i < nloc; i += 256)
+      if (bs + i < (unsigned)CAND_MAX) w.cand[row * CAND_MAX + bs + i] = lbuf[rl * SK_LCAP + i];
+  }
+}
+
 // one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
 __global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k) {
   __shared__ unsigned part[256];
@@ -339,19 +535,44 @@ __global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int 
 // expected tail count is >= 1.25 k (k = 2048: +11 sigma) and go straight to the collect pass.  The result is still
 // the EXACT top-k of the keys as long as a row collected >= k candidates; otherwise `redo` is raised and the exact
 // histogram passes below run (they early-exit on the flag, so the common case pays only their launch).
+__device__ __forceinline__ float row16_max(float m) {   // maximum over the lane's DPP row (16 lanes); every lane gets it
+#define MK_ROR_MAX(n) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + n, 0xf, 0xf, false)))
+  MK_ROR_MAX(1); MK_ROR_MAX(2); MK_ROR_MAX(4); MK_ROR_MAX(8);
+#undef MK_ROR_MAX
+  return m;
+}
+
+// histogram of p (analytic threshold) and, in the same read, the largest valid p of every 16 consecutive cells (w.pmax: the
+// rate bound of the skip sampler below).  A workgroup's cell range starts at a multiple of 256, a wave reads 64 consecutive
+// cells per iteration: a 16-cell block is one DPP row.
 __global__ __launch_bounds__(256) void exprace_phist_kernel(const float* __restrict__ p, TopkWork w, long long ncell) {
   __shared__ unsigned sh[NBINS];
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < NBINS; i += 256) sh[i] = 0;
   __syncthreads();
-  const long long per = (ncell + gridDim.x - 1) / gridDim.x;
+  const long long per = ((ncell + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
   const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
   const float* pb = p + (long long)b * ncell;
+  float* pm = w.pmax + (long long)b * w.nblk;
   bool bad = false;
-  for (long long c = c0 + threadIdx.x; c < c1; c += 256) {
-    const float pv = pb[c];
-    bad |= !(pv >= 0.f) || isinf(pv);
-    if (pv > 0.f && !isinf(pv)) atomicAdd(&sh[__float_as_uint(pv) >> 20], 1u);
+  for (long long base = c0; base < c1; base += 1024) {   // (uniform trip count: the DPP reduction needs whole rows)
+    float pv[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // four loads in flight per thread
+      const long long c = base + u * 256 + threadIdx.x;
+      in[u] = c < c1;
+      pv[u] = in[u] ? pb[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long c = base + u * 256 + threadIdx.x;
+      bad |= !(pv[u] >= 0.f) || isinf(pv[u]);
+      const bool ok = pv[u] > 0.f && !isinf(pv[u]);
+      if (ok) atomicAdd(&sh[__float_as_uint(pv[u]) >> 20], 1u);
+      const float m = row16_max(ok ? pv[u] : 0.f);
+      if ((threadIdx.x & 15) == 0 && in[u]) pm[c >> 4] = m;
+    }
   }
   if (bad && w.invalid) atomicOr(w.invalid, 1);
   __syncthreads();
@@ -1094,7 +1315,9 @@ __global__ void finalize_kernel(float* R, float* t, float* conf, const int* inva
   if (i < B) conf[i] = 0.f;
 }
 
-TopkWork carve(void* work, int R, int B) {
+int g_exprace_mode = 0;   // dev (mk_exprace_set_mode): 0 = skip sampler, 1 = the 6-bit pre-filter pass
+
+TopkWork carve(void* work, int R, int B, long long ncell) {
   TopkWork w;
   char* p = (char*)work;
   w.hist = (unsigned*)p;  p += (size_t)R * NBINS * 4;
@@ -1103,7 +1326,9 @@ TopkWork carve(void* work, int R, int B) {
   w.phist = (unsigned*)p; p += (size_t)B * NBINS * 4;
   w.redo = (int*)p;       p += 4;
   p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-  w.cand = (unsigned long long*)p;
+  w.cand = (unsigned long long*)p;  p += (size_t)R * CAND_MAX * 8;
+  w.nblk = (ncell + SK_CELLS - 1) / SK_CELLS;
+  w.pmax = (float*)p;
   return w;
 }
 
@@ -1111,10 +1336,15 @@ TopkWork carve(void* work, int R, int B) {
 
 extern "C" {
 
-long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k) {
+long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k, long long ncell) {
   (void)k;
   const long long R = (long long)B * rows_per_pair;
-  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4 + 16 + R * CAND_MAX * 8;
+  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4 + 16 + R * CAND_MAX * 8 + (long long)B * ((ncell + SK_CELLS - 1) / SK_CELLS) * 4;
+}
+int mk_exprace_set_mode(int mode) {
+  MK_CHECK_ARG(mode == 0 || mode == 1, "mk_exprace_set_mode: 0 (skip sampler) or 1 (pre-filter pass)");
+  g_exprace_mode = mode;
+  return MK_OK;
 }
 
 int mk_counter_add(unsigned long long* counter, unsigned long long inc, mk_stream_t stream) {
@@ -1134,7 +1364,7 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   MK_CHECK_ARG(((uintptr_t)work & 15) == 0, "mk_exprace_topk: work must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int R = B * rows_per_pair;
-  TopkWork w = carve(work, R, B);
+  TopkWork w = carve(work, R, B, ncell);
   w.invalid = invalid;
   w.pair_base = pair_base;
   const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + 1;
@@ -1157,7 +1387,11 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   // the block-local cell index must fit 16 bits of a queue entry: more cell blocks for very large matrices
   int pcb = cb;
   while ((ncell + pcb - 1) / pcb > 65536) pcb *= 2;
-  if (!noise && rows_per_pair <= PF_MAXROWS) {
+  if (!noise && rows_per_pair <= PF_MAXROWS && g_exprace_mode == 0) {
+    // (the walk geometry is a function of ncell alone: a pair's draws do not depend on the batch)
+    hipLaunchKernelGGL(exprace_skip_kernel, dim3((unsigned)((w.nblk + SK_RANGE - 1) / SK_RANGE), (rows_per_pair + SK_ROWS - 1) / SK_ROWS, B),
+                       dim3(256), 0, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+  } else if (!noise && rows_per_pair <= PF_MAXROWS) {
     const size_t lds = (size_t)rows_per_pair * PF_LCAP * 8 + (size_t)PF_QCAP * 4;
     hipLaunchKernelGGL(exprace_prefilter_kernel, dim3(pcb, B), dim3(256), lds, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair,
                        ncell);

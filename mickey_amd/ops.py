@@ -367,6 +367,11 @@ def counter_add(counter, inc):
     call("mk_counter_add", ptr(counter), int(inc), stream())
 
 
+def exprace_set_mode(mode):
+    """Dev knob (mickey_hip_dev.h): 0 = skip sampler (default), 1 = the pre-filter collect pass."""
+    call("mk_exprace_set_mode", int(mode))
+
+
 def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None, pair_base=0):
     """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
     p, noise = _c(p, noise)
@@ -375,7 +380,7 @@ def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None
     dev = p.device
     idx = torch.empty((B * rows_per_pair, k), device=dev, dtype=torch.int32)
     cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
-    work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k),), device=dev, dtype=torch.uint8)
+    work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k, ncell),), device=dev, dtype=torch.uint8)
     call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(offset_dev), ptr(idx), ptr(cnt), ptr(invalid), ptr(work),
          B, rows_per_pair, ncell, k, int(pair_base), stream())
     return idx, cnt

@@ -50,7 +50,7 @@ def test_abi_rejects_bad_arguments_without_a_device(nv):
     # row partials (4 column chunks) + column partials (1 row block) + final LSE vectors + pad + the stored correlation
     assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 1) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4 + 2 * 10 * 12
     assert nv.query("mk_dual_softmax_work_floats", 2, 10, 12, 0) == 2 * 4 * 10 * 2 + 2 * 1 * 12 * 2 + 2 * 2 * 12 + 4
-    assert nv.query("mk_exprace_topk_work_bytes", 1, 20, 2048) > 20 * 8192 * 8
+    assert nv.query("mk_exprace_topk_work_bytes", 1, 20, 2048, 1938 * 1938) > 20 * 8192 * 8 + 1938 * 1938 // 16 * 4
     with pytest.raises(nv.MickeyHipError):
         nv.call("mk_flash_attn_fwd", None, None, None, None, 0, 0, 0, 0, 0, 0, None)
 

@@ -94,7 +94,7 @@ def test_sampler_exact_fallback(scale):
     _assert_same_sample(idx, ref, keys)
 
 
-def test_sampler_philox_properties():
+def test_sampler_philox_properties(sampler_mode):
     from mickey_amd import ops
     dev = _dev()
     data, _, _ = _problem(B=2)
@@ -122,10 +122,21 @@ def test_sampler_philox_properties():
     assert first > second
 
 
-def test_sampler_prefilter_many_rows_and_frequencies():
-    """The Philox collect pass draws the uniforms in two parts (6-bit pre-filter + 18 low bits for the survivors; rows in
-    groups of 20 per stage-1 call).  40 rows exercise two groups; inclusion frequencies of a skewed 4096-cell problem over
-    40 rows x 30 calls must match torch.multinomial's (two-sample chi-square), and every row is a valid draw."""
+@pytest.fixture(params=[0, 1], ids=["skip_sampler", "prefilter_pass"])
+def sampler_mode(request):
+    """Both on-device generators of the race (mk_exprace_set_mode): the product path (candidates by geometric skipping) and the
+    pass that tests every (row, cell) behind a 6-bit pre-filter."""
+    from mickey_amd import ops
+    ops.exprace_set_mode(request.param)
+    yield request.param
+    ops.exprace_set_mode(0)
+
+
+def test_sampler_many_rows_and_frequencies(sampler_mode):
+    """On-device draws, 40 rows per pair (several row groups of either generator): inclusion frequencies of a skewed 4096-cell
+    problem over 40 rows x 30 calls must match torch.multinomial's (two-sample chi-square), and every row is a valid draw.
+    (k / ncell = 6 %: the skip sampler takes its dense branch for most blocks here; the 10 000-cell test in
+    test_bench_config_gpu.py and the one below run its skipping branch.)"""
     from mickey_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(11)
@@ -139,7 +150,7 @@ def test_sampler_prefilter_many_rows_and_frequencies():
         assert (cnt.cpu() == k).all()
         srt = torch.sort(idx, -1).values
         assert bool((srt[:, 1:] != srt[:, :-1]).all())
-        assert not torch.equal(idx[3], idx[23])    # rows of different stage-1 groups are different draws
+        assert not torch.equal(idx[3], idx[23])    # rows of different groups are different draws
         f_hip += torch.bincount(idx.reshape(-1), minlength=ncell).double()
     f_ref = torch.bincount(torch.multinomial(p.expand(rows * 30, ncell), k, generator=g).reshape(-1), minlength=ncell).double()
     keep = (f_hip + f_ref) >= 10
@@ -148,7 +159,61 @@ def test_sampler_prefilter_many_rows_and_frequencies():
     assert chi2 < dof + 6 * (2 * dof) ** 0.5, (chi2, dof)
 
 
-def test_sampler_degenerate_inputs():
+def test_sampler_first_draw_is_categorical_and_sparse_frequencies(sampler_mode):
+    """(a) The first index of a row is the arg-max of the race keys = ONE categorical draw ~ p (what torch.multinomial draws
+    first): one-sample chi-square of 61 440 first draws against p / sum(p).  This pins the law of the race KEYS the on-device
+    generators produce (the skip sampler draws them from Exp(1) conditioned on the key clearing the threshold), not only which
+    cells are included.  (b) 65 536 cells, k = 256 (inclusion ~4e-3: the skipping branch, several workgroup ranges, a few
+    dominant cells that turn their blocks dense): two-sample chi-square of the inclusion counts against torch.multinomial."""
+    from mickey_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    ncell, k, rows, B = 3000, 128, 40, 64
+    p = torch.rand(ncell, generator=g) ** 4 + 1e-3
+    p[::11] = 0.0
+    p[5] = 40.0                                   # one dominant cell
+    pd = p.to(dev)[None].repeat(B, 1).contiguous()
+    first = torch.zeros(ncell, dtype=torch.float64)
+    for call in range(24):
+        idx, cnt = ops.exprace_topk(pd, rows, k, seed=21, offset=call)
+        first += torch.bincount(idx[:, 0].cpu().long(), minlength=ncell).double()
+    n = first.sum()
+    assert n == 24 * B * rows
+    exp = (p.double() / p.double().sum()) * n
+    sel = exp >= 8
+    rest_o, rest_e = first[~sel].sum(), exp[~sel].sum()
+    chi2 = float((((first - exp) ** 2) / exp)[sel].sum() + (rest_o - rest_e) ** 2 / max(float(rest_e), 1e-9))
+    df = int(sel.sum())
+    assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
+    assert float(first[::11].sum()) == 0.0
+
+    ncell, k, rows, B = 65536, 256, 20, 8
+    p = torch.rand(ncell, generator=g) ** 8 + 1e-5
+    p[torch.randperm(ncell, generator=g)[:40]] += 2.0
+    pd = p.to(dev)[None].repeat(B, 1).contiguous()
+    f_hip = torch.zeros(ncell, dtype=torch.float64)
+    for call in range(12):
+        idx, cnt = ops.exprace_topk(pd, rows, k, seed=9, offset=call, pair_base=8 * call)
+        assert int(cnt.min()) == k
+        srt = idx.long().sort(dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+        f_hip += torch.bincount(idx.reshape(-1).cpu().long(), minlength=ncell).double()
+    torch.manual_seed(2)
+    f_ref = torch.zeros(ncell, dtype=torch.float64)
+    for _ in range(12):
+        f_ref += torch.bincount(torch.multinomial(pd[0][None].expand(B * rows, -1), k).reshape(-1).cpu(), minlength=ncell).double()
+    # pool the many low-count cells by magnitude of p so that every bin is populated
+    order = torch.argsort(p)
+    a, b = f_hip[order], f_ref[order]
+    nb = 512
+    a, b = a.reshape(nb, -1).sum(1), b.reshape(nb, -1).sum(1)
+    sel = (a + b) >= 20
+    df = int(sel.sum()) - 1
+    chi2 = float((((a - b) ** 2) / (a + b))[sel].sum())
+    assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
+
+
+def test_sampler_degenerate_inputs(sampler_mode):
     from mickey_amd import ops
     dev = _dev()
     p = torch.zeros((2, 5000))
