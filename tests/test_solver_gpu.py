@@ -213,6 +213,33 @@ def test_sampler_first_draw_is_categorical_and_sparse_frequencies(sampler_mode):
     assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
 
 
+def test_sampler_queue_overflow_takes_the_exact_fallback():
+    """One spike per 16-cell block: every block of the skip sampler's walk is a hit for most rows (rate bound 0.08 per cell, just
+    under the dense cut), ~3000 hits per row where the workgroup's queue holds 1024 -> `redo` is raised on the device and the
+    exact histogram passes redo the call.  The result must still be a valid weighted draw: k distinct cells, (almost) all of
+    them spikes, inclusion counts of the spikes flat (chi-square against the uniform expectation)."""
+    from mickey_amd import ops
+    dev = _dev()
+    ncell, k, rows, B = 65536, 256, 20, 4
+    p = torch.full((ncell,), 1e-7)
+    spikes = torch.arange(0, ncell, 16) + 5
+    p[spikes] = 1.0
+    pd = p.to(dev)[None].repeat(B, 1).contiguous()
+    counts = torch.zeros(ncell, dtype=torch.float64)
+    for call in range(6):
+        idx, cnt = ops.exprace_topk(pd, rows, k, seed=4, offset=call)
+        assert int(cnt.min()) == k
+        srt = idx.long().sort(dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+        counts += torch.bincount(idx.reshape(-1).cpu().long(), minlength=ncell).double()
+    on = counts[spikes]
+    assert on.sum() >= 0.995 * counts.sum()
+    exp = on.sum() / len(spikes)
+    chi2 = float(((on - exp) ** 2 / exp).sum())
+    df = len(spikes) - 1
+    assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
+
+
 def test_sampler_degenerate_inputs(sampler_mode):
     from mickey_amd import ops
     dev = _dev()
