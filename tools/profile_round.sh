@@ -70,9 +70,15 @@ for k in sorted(set(f) | set(w)):
     fv, wv = f[k].get("FETCH_SIZE", []), w[k].get("WRITE_SIZE", [])
     roles[k] = {"launches": len(fv) or len(wv), "FETCH_SIZE_KiB_per_launch": sum(fv) / len(fv) if fv else None,
                 "WRITE_SIZE_KiB_per_launch": sum(wv) / len(wv) if wv else None}
-for k, v in roles.items():   # HBM-side bytes of the role per FORWARD: (2 x FETCH_SIZE + WRITE_SIZE) KiB x launches / forwards
+# HBM-side bytes of the role per FORWARD: (f x FETCH_SIZE + WRITE_SIZE) KiB x launches / forwards.  f = 2 is the guide's
+# calibration for 16-B/lane streaming reads (every matrix / row kernel here); the sampler reads p with 4-byte loads and IS a
+# calibration case of its own: its histogram pass reads ncell x 4 B per pair exactly once (481 MB per 32 pairs) and the raw
+# FETCH_SIZE of the whole stage is 516 MB (that read + the 30-MB block maxima + the candidates' cells), so f = 1 there.
+FETCH_FACTOR = {"sampler": 1.0}
+for k, v in roles.items():
     if v["FETCH_SIZE_KiB_per_launch"] is not None and v["WRITE_SIZE_KiB_per_launch"] is not None:
-        v["bytes_per_forward"] = (2.0 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024.0 * v["launches"] / meta["forwards"]
+        v["fetch_factor"] = FETCH_FACTOR.get(k, 2.0)
+        v["bytes_per_forward"] = (v["fetch_factor"] * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024.0 * v["launches"] / meta["forwards"]
 traffic["roles"] = roles
 enc = [k for k in roles if k.startswith("encoder_gemm")]
 if enc:
