@@ -31,7 +31,29 @@ def _auto_tile():
     if torch.cuda.is_available():
         from mickey_amd import ops
         ops.gemm_set_tile(0)
+        ops.gemm_set_tile(400)   # tile order back to automatic
         ops.attn_set_mode(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(3878, 3072, 1024), (5000, 1024, 512), (2100, 1280, 256)])
+def test_gemm_tile_orders_are_bit_identical(M, N, K):
+    """The 256x256 kernel's tile ORDER (bands of b m-tiles / groups of g n-tiles, automatic = n-fastest for outputs <= 4 tiles
+    wide) only permutes which workgroup computes which tile: every order gives the same bits, including group widths that do not
+    divide the number of n-tiles (12 = 8 + 4, 5 = 4 + 1, 5 = 3 + 2)."""
+    from mickey_amd import ops
+    dev = _dev()
+    a = (torch.randn((M, K), generator=g(1)) * 0.5).bfloat16().to(dev)
+    w = (torch.randn((N, K), generator=g(2)) / math.sqrt(K)).bfloat16().to(dev)
+    bias = torch.randn((N,), generator=g(3)).to(dev)
+    ops.gemm_set_tile(7)
+    outs = {}
+    for order in (400, 408, 403, 464 + 3, 464 + 4, 464 + 8, 464 + 12):
+        ops.gemm_set_tile(order)
+        outs[order] = ops.gemm(a, w, bias, act=ops.ACT_GELU, out_f32=False)
+    ref = a.float() @ w.float().t() + bias
+    assert rel(outs[400].float(), F.gelu(ref)) < 5e-3
+    for order, o in outs.items():
+        assert torch.equal(o, outs[400]), order
 
 
 @pytest.mark.parametrize("tile", [1, 2, 7])
