@@ -4,17 +4,21 @@
 // The reference materialises a [20B, n*n] tiled copy of final_scores (300 MB / pair), a same-sized
 // Exp(1) noise tensor and a full top-k for its outer torch.multinomial, then tiles X/Y 100x for the
 // inner one.  Here:
-//   * mk_exprace_topk: a threshold from the histogram of p alone (expected tail count of the race keys), ONE collect
-//     pass with Philox noise generated in registers (uniforms drawn in two parts: a 6-bit pre-filter for all rows of a
-//     cell from one call, the low bits only for the 1-in-64 survivors; injected noise: one streamed read per group of 4
-//     rows), small in-LDS bitonic sort -> the same "top-k of p / Exp(1)" selection, in the same (descending key) order
-//     torch.topk returns; an exact radix-histogram path takes over on device if a row collected too few / too many.
+//   * mk_exprace_topk: one read of p gives its histogram -- hence the threshold T of the race keys whose EXPECTED tail count
+//     is 1.25 k, a function of p alone -- and the maximum of every 16 cells; the candidates {p / e > T} of a row are then
+//     generated, not searched for (exprace_skip_kernel: geometric skipping under the 16-cell bound, thinning, keys drawn from
+//     Exp(1) conditioned on clearing T: the law of drawing every e, RNG work proportional to the ~2600 candidates of a row
+//     instead of its 3.76 M cells); small in-LDS bitonic sort -> the same "top-k of p / Exp(1)" selection, in the same
+//     (descending key) order torch.topk returns; an exact radix-histogram path takes over on device if a row collected too
+//     few / too many.  Injected noise (tests): every (row, cell) is keyed, one streamed read per group of 4 rows.  The
+//     round-3 generator (every cell tested behind a 6-bit pre-filter) is kept as the A/B partner (mk_exprace_set_mode).
 //   * mk_train_ransac_masks / mk_reinforce_scatter: the training-time RANSAC of loss/loss_class.py (8-point hypotheses,
 //     refinement of every hypothesis, REINFORCE bookkeeping).
 //   * mk_ransac_hypotheses: a correspondence set (X, Y, w: 56 KB) is staged once in LDS and shared by
-//     all its hypotheses; one wave per hypothesis: exponential-race 3-sample (wave arg-max), 3x3
-//     Kabsch via one-sided Jacobi SVD in fp64 (warp-serial, no MFMA), soft inlier count by wave64
-//     reduction.
+//     all its hypotheses; a hypothesis draws its 3 correspondences ~ w without replacement with three uniforms (prefix
+//     sums of the set's weights in LDS, binary search with the chosen ones masked out = the top-3 of an exponential race,
+//     which the injected-noise path still runs), 3x3 Kabsch via one-sided Jacobi SVD in fp64 (one per lane, no MFMA), soft
+//     inlier count by wave64 reduction.
 //   * mk_refine_pose: one workgroup per pair: arg-max, <= 4 masked-Kabsch refits with the reference's
 //     per-pair early exit, final confidence.  No host synchronisation anywhere.
 // Noise can be INJECTED (fp32 Exp(1) tensors / explicit indices) so that tests are bit-comparable
