@@ -337,7 +337,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the vit_small and config5 legs")
-    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, ref_split_fp32mfma, vit_small, config5)")
+    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, ref_split_fp32mfma, attn_mfma16, vit_small, config5)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step sustained leg")
     ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no sustained / PCIe / "
                                                          "single-pair / CPU legs (profiling passes)")
@@ -662,6 +662,9 @@ def main(argv=None):
         if args.legs is not None and name not in args.legs.split(","):
             return
         bp = batch_pairs or B
+        attn_mode = mk.pop("attn_mode", None)   # dev knob (process-wide): set for this leg only
+        if attn_mode is not None:
+            ops.attn_set_mode(attn_mode)
         m, _, _ = make_model(dtype, **mk)
         d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=bp, H=hw[0], W=hw[1], seed=1234).items()}
         a = argparse.Namespace(**vars(args))
@@ -681,6 +684,8 @@ def main(argv=None):
                 ent["roofline"] = {k: dom[0][k] for k in ("stage", "bound", "achieved", "peak", "unit", "frac")}
         del m, d
         torch.cuda.empty_cache()
+        if attn_mode is not None:
+            ops.attn_set_mode(args.attn_mode)
         out.setdefault("legs", {})[name] = ent
 
     if single and not args.no_alt and args.dtype == "bf16":
@@ -695,6 +700,10 @@ def main(argv=None):
             out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
                           "note": "= legs.fp16 (kept for readers of the round-2 line)"}
     if single and not args.no_legs:
+        leg("attn_mfma16", "the headline configuration with the attention kernel on v_mfma_f32_16x16x32 (mk_attn_set_mode 5; the "
+            "cheaper shape per flop at the power limit, LABNOTES R4.11 / R4.13).  Not the default: a single pair is 12-17 %% "
+            "slower with it, and ONE kernel family has to serve every batch size for a pair's result not to depend on its batch",
+            args.dtype, args.steps, args.warmup, dominant="attention", attn_mode=5)
         leg("vit_small", "DINOv2 ViT-S/14 encoder (the size north_star names; 305 GFLOP per pair, attention 46 %% of it) "
             "+ the same heads / matcher / solver, %d pairs of 540x720" % B, args.dtype, max(5, args.steps // 2), 2,
             arch="vit_small", dominant="attention")

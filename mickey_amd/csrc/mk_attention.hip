@@ -395,6 +395,195 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
   }
 }
 
+// The same kernel on v_mfma_f32_16x16x32 (modes 4 / 5).  At the socket power limit the 16x16x32 shape gets ~15 % more flops
+// through the matrix pipe than 32x32x16 (tools/micro/mfma_power.hip: 2.05 vs 1.79 PFLOP/s on random bf16 operands), and this
+// kernel is bound by energy like the GEMMs.  Layout: S^T = K.Q^T in 16-key x 16-query blocks -- after the MFMA lane (n, g) =
+// (lane & 15, lane >> 4) holds keys 16 kb + 4 g .. + 3 of query n, so a query's 64 scores of a tile sit in 4 lanes (row sums /
+// maxima: two lane exchanges, once per kernel / per re-base).  O^T = V^T.P^T in 32-key steps: k-slot 8 g + e of a step is key
+// 32 s + 4 g + e (e < 4) or 32 s + 16 + 4 g + e - 4 -- what the lane already holds of key blocks 2 s and 2 s + 1 -- so the
+// V^T operand is two 8-byte LDS reads (the quads 4 g of both blocks, at their key-permuted positions) instead of one 16-byte
+// read; everything else (staging, lean softmax, re-base rule, operation order per query) is the kernel above.
+template <typename T, int QB>
+__global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold16_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                                const T* __restrict__ vt, T* __restrict__ out,
+                                                                                int ldo, int heads, int ntok, int ntok_pad) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlock ab = attn_block();
+  const int head = ab.head, img = ab.img;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = ab.qblk * (128 * QB) + wave * (32 * QB);
+  const int n = lane & 15, g = lane >> 4;
+  const bool wave_has_queries = q0 < ntok;
+
+  V8 qf[QB][2][2];   // [32-query block][16-query half][32-wide d step]
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      int qrow = q0 + qb * 32 + nb * 16 + n;
+      qrow = qrow < ntok_pad ? qrow : ntok_pad - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qf[qb][nb][ks] = *(const V8*)(Qh + (long long)qrow * 64 + ks * 32 + g * 8);
+    }
+  const int srow = lane >> 3, sp = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * KV_TILE_BYTES;
+    char* sV = sK + KV_TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ii = wave * 2 + t;
+      const int r = ii * 8 + srow;
+      glds16(Kh + (long long)(kt * 64 + r) * 64 + swz8(r, sp) * 8, sK + ii * 1024);
+      glds16(Vh + (long long)r * ntok_pad + kt * 64 + swz8(r, sp) * 8, sV + ii * 1024);
+    }
+  };
+
+  f32x4 o[QB][2][4], negm[QB][2];
+  float m_run[QB][2], l_run[QB][2];   // l_run: this lane's share of the row sum (the 4 lanes of a query are added at the end)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[qb][nb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      negm[qb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      m_run[qb][nb] = l_run[qb][nb] = 0.f;
+    }
+  bool first = true;
+  // position quad of key quad g inside a 16-key block (mk_gemm_qkv stores V^T with token bits 2 <-> 3 swapped)
+  const int pq = ((g & 1) << 1) | (g >> 1);
+
+  const int nkt = (ntok + 63) >> 6;
+  stage(0, 0);
+  auto kv_tile = [&](const int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!LAST) stage((kt + 1) & 1, kt + 1);
+    if (!wave_has_queries) return;
+    const char* sK = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+    const char* sV = sK + KV_TILE_BYTES;
+
+    f32x4 s[QB][2][4];   // [qb][nb][16-key block]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // (d step outside: consecutive MFMAs go to different accumulators)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int row = kb * 16 + n;
+        const V8 kf = *(const V8*)(sK + row * 128 + swz8(row, ks * 4 + g) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            s[qb][nb][kb] = Lp<T>::mma16(kf, qf[qb][nb][ks], ks == 0 ? negm[qb][nb] : s[qb][nb][kb]);   // S' = K.Q^T - m
+      }
+    }
+    V8 pf[QB][2][2];   // [qb][nb][32-key step]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        if (LAST && (ntok & 63)) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kt * 64 + kb * 16 + 4 * g + r >= ntok) s[qb][nb][kb][r] = -1e30f;
+        }
+        auto exp_sum = [&]() {   // P = 2^S' and this lane's share of the row sum (see the kernel above)
+          float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = __builtin_amdgcn_exp2f(s[qb][nb][kb][r]);
+              pf[qb][nb][kb >> 1][(kb & 1) * 4 + r] = (T)pv;
+              rs4[r] += pv;
+            }
+          return (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+        };
+        float rs = 0.f;
+        bool rebase = first;
+        if (!first) {
+          rs = exp_sum();
+          rebase = __any(!(rs <= ATT_REBASE_SUM));
+        }
+        if (rebase) {
+          float t4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t4[r] = fmaxf(fmaxf(s[qb][nb][0][r], s[qb][nb][1][r]), fmaxf(s[qb][nb][2][r], s[qb][nb][3][r]));
+          float mx = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float shift = first ? mx : fmaxf(mx, 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+          for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              o[qb][nb][b4][i] *= alpha;
+              s[qb][nb][b4][i] -= shift;
+            }
+          l_run[qb][nb] *= alpha;
+          m_run[qb][nb] += shift;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) negm[qb][nb][i] = -m_run[qb][nb];
+          rs = exp_sum();
+        }
+        l_run[qb][nb] += rs;
+      }
+    first = false;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {   // (key step outside, as above)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int row = db * 16 + n;
+        const int c1 = st * 4 + (pq >> 1);
+        const u32x2_t lo = *(const u32x2_t*)(sV + row * 128 + swz8(row, c1) * 16 + (pq & 1) * 8);
+        const u32x2_t hi = *(const u32x2_t*)(sV + row * 128 + swz8(row, c1 + 2) * 16 + (pq & 1) * 8);
+        const V8 vf = __builtin_bit_cast(V8, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) o[qb][nb][db] = Lp<T>::mma16(vf, pf[qb][nb][st], o[qb][nb][db]);
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt - 1; ++kt) kv_tile(kt, std::false_type{});
+  kv_tile(nkt - 1, std::true_type{});
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float l = l_run[qb][nb];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      const int qi = q0 + qb * 32 + nb * 16 + n;
+      if (qi < ntok) {
+        T* orow = out + ((long long)img * ntok + qi) * ldo + head * 64;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          V4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (T)(o[qb][nb][db][e] * inv);
+          *(V4*)(orow + db * 16 + g * 4) = w;
+        }
+      }
+    }
+}
+
 int g_attn_mode = 0;   // mk_attn_set_mode: 0 automatic, 1 / 2: the fold kernel with 32 / 64 queries per wave, 3: classic online softmax (64 q/wave)
 
 template <typename T>
@@ -411,6 +600,12 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
   else if (mode == 2)
     hipLaunchKernelGGL((attn_fwd_fold_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  else if (mode == 4)
+    hipLaunchKernelGGL((attn_fwd_fold16_kernel<T, 1>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  else if (mode == 5)
+    hipLaunchKernelGGL((attn_fwd_fold16_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
@@ -419,7 +614,7 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }  // namespace
 
 extern "C" int mk_attn_set_mode(int mode) {
-  MK_CHECK_ARG(mode >= 0 && mode <= 3, "mk_attn_set_mode: 0 automatic, 1 / 2 = lean softmax with 32 / 64 queries per wave, 3 = classic online softmax");
+  MK_CHECK_ARG(mode >= 0 && mode <= 5, "mk_attn_set_mode: 0 automatic, 1 / 2 = lean softmax with 32 / 64 queries per wave, 3 = classic online softmax, 4 / 5 = 1 / 2 on the 16x16x32 MFMA");
   g_attn_mode = mode;
   return MK_OK;
 }

@@ -440,11 +440,12 @@ def test_layernorm_groups_and_bordered_output(D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("ntok,nimg,heads", [(64, 2, 3), (200, 2, 3), (1939, 2, 3), (1939, 8, 8), (300, 32, 16)])
 def test_flash_attention(dtype, ntok, nimg, heads, mode):
     """(1939, 8, 8) and (300, 32, 16) are large enough grids to take the 64-queries-per-wave instantiation in auto mode;
-    modes 1 / 2 = the production kernel (lean softmax) with 32 / 64 queries per wave, 3 = the classic online softmax."""
+    modes 1 / 2 = the production kernel (lean softmax) with 32 / 64 queries per wave, 3 = the classic online softmax,
+    4 / 5 = the production kernel's structure on the 16x16x32 MFMA."""
     from mickey_amd import ops
     dev = _dev()
     ops.attn_set_mode(mode)
@@ -476,6 +477,27 @@ def test_flash_attention(dtype, ntok, nimg, heads, mode):
         ops.flash_attn(q.to(dev), k.to(dev), vt.to(dev), out2, nimg, heads, ntok, pad)
         assert torch.equal(out, out2)
 
+
+
+@pytest.mark.parametrize("pair", [(1, 2), (4, 5)])
+def test_flash_attention_queries_per_wave_bit_identical(pair):
+    """32 and 64 queries per wave of one kernel family (32x32x16: modes 1 / 2, 16x16x32: modes 4 / 5) perform the same
+    operations per query in the same order: bit-identical outputs -- what lets the automatic choice depend on the grid size
+    (one pair vs a batch) without a pair's result depending on its batch."""
+    from mickey_amd import ops
+    dev = _dev()
+    nimg, heads, ntok, pad = 3, 4, 1939, 1984
+    gq = torch.Generator(device="cpu").manual_seed(5)
+    q = (torch.randn((nimg, heads, pad, 64), generator=gq) * 0.3).bfloat16().to(dev)
+    k = torch.randn((nimg, heads, pad, 64), generator=gq).bfloat16().to(dev)
+    vt = torch.randn((nimg, heads, 64, pad), generator=gq).bfloat16().to(dev)
+    outs = []
+    for mode in pair:
+        ops.attn_set_mode(mode)
+        out = torch.zeros((nimg * ntok, heads * 64), device=dev, dtype=torch.bfloat16)
+        ops.flash_attn(q, k, vt, out, nimg, heads, ntok, pad)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 def _to_bordered(x, nimg, H, W):

@@ -11,7 +11,7 @@ from tools.bench_kernels import timeit  # noqa: E402
 
 modes = [int(t) for t in sys.argv[1:]] or [1, 2, 3]
 dev = torch.device("cuda:0")
-nimg, heads, ntok, pad = 64, 16, 1939, 1984
+nimg, heads, ntok, pad = int(os.environ.get("NIMG", "64")), 16, 1939, 1984
 q = (torch.randn((nimg, heads, pad, 64), device=dev) * 0.2).bfloat16()
 k = torch.randn((nimg, heads, pad, 64), device=dev).bfloat16()
 vt = torch.randn((nimg, heads, 64, pad), device=dev).bfloat16()
@@ -23,4 +23,4 @@ for rep in range(5):
         ts[m].append(timeit(lambda: ops.flash_attn(q, k, vt, out, nimg, heads, ntok, pad), iters=10, warm=2))
 ops.attn_set_mode(0)
 fl = 4.0 * nimg * heads * ntok * ntok * 64
-print("attention 64 x 16 x 1939: " + "  ".join("mode%d %6.1f TF (%.3f ms)" % (m, fl / statistics.median(ts[m]) / 1e12, statistics.median(ts[m]) * 1e3) for m in modes))
+print("attention %d x 16 x 1939: " % nimg + "  ".join("mode%d %6.1f TF (%.3f ms)" % (m, fl / statistics.median(ts[m]) / 1e12, statistics.median(ts[m]) * 1e3) for m in modes))
