@@ -2,6 +2,7 @@
 include/mickey_hip.h declares, argument validation works without a device, config / checkpoint
 contract, BatchNorm folding, the lib.* drop-in import paths."""
 import copy
+import math
 import os
 import re
 
@@ -286,3 +287,31 @@ def test_bordered_index_matches_the_library():
                     assert (n in pix) == inside
                     if inside:
                         assert n == idx[(b * H + y + dy) * W + x + dx]
+
+
+def test_split_operand_scheme_is_fp32_grade():
+    """The arithmetic behind mk_conv3x3_split / mk_gemm_grouped_split / mk_dual_softmax_split, emulated on the CPU with the
+    host-side preparation the product uses (weights.split_conv_weight): x * 64 and w * scale as hi + lo fp16 planes, three
+    sweeps lo.hi + hi.lo + hi.hi with fp32-or-better accumulation, scaled back by 1 / (64 scale).  The dropped lo.lo term and
+    the planes' rounding leave ~22 bits: <= 2e-6 relative against the exact fp64 product -- also for weights so large
+    (BatchNorm folded over a tiny variance) that the plane scale has to come down, and for activations near the planes' range."""
+    import torch
+    from mickey_amd import ops, weights
+    g = torch.Generator().manual_seed(0)
+    for wmag, xmag in ((0.05, 1.0), (30.0, 1.0), (0.05, 150.0)):   # |x| * 64 stays inside fp16 (the planes clamp beyond +-1023)
+        K, Cout, M = 1152, 96, 200
+        w = torch.randn((Cout, K), generator=g) * wmag
+        x = torch.randn((M, K), generator=g) * xmag
+        sw = weights.split_weight_scale(w)
+        assert sw == 2.0 ** round(math.log2(sw)) and float(w.abs().max()) * sw <= 32768.0
+        planes = weights.split_conv_weight(w, sw)                 # [Cout, 3K] = [W_hi | W_lo | W_hi]
+        w_hi, w_lo = planes[:, :K].double(), planes[:, K:2 * K].double()
+        assert torch.equal(planes[:, 2 * K:], planes[:, :K])
+        xs = x * ops.SPLIT_ACT_SCALE
+        x_hi = xs.clamp(-65504.0, 65504.0).to(torch.float16)
+        x_lo = (xs - x_hi.float()).to(torch.float16)
+        acc = x_lo.double() @ w_hi.t() + x_hi.double() @ w_lo.t() + x_hi.double() @ w_hi.t()
+        out = acc / (ops.SPLIT_ACT_SCALE * sw)
+        ref = x.double() @ w.double().t()
+        err = float((out - ref).norm() / ref.norm())
+        assert err < 2e-6, (wmag, xmag, err)
