@@ -10,18 +10,18 @@ read).  Weak scaling: every rank processes its own B pairs.
 rendezvous on 127.0.0.1) unless the script already runs under torch.distributed.run; it fails loudly when
 the node has fewer than N GPUs.  ``n_gpus`` in the output is the number of ranks RCCL saw.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with
+Rank 0 prints ONE COMPACT JSON line (< 3 KB: the driver keeps an 8-KB tail of stdout) as the LAST line of stdout with
   roofline     -- the dominant kernel (the 16-bit MFMA GEMM of the encoder linears): algorithmic FLOPs of
-                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s;
-                  roofline.stages lists every stage the same way (attention, conv-GEMM, LayerNorm, matcher,
-                  sampler against their governing peak; hypotheses / refinement: time only)
+                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s
+  stages       -- the six largest stages: ms per step and fraction of their governing peak
   cpu_baseline -- the CPU oracle (torch-CPU fp32 restatement of the reference) timed on this box's host
-                  cores on a bounded sample (1 pair; 1 warm-up + median of 3, per stage), N = 1 only
-  legs         -- the same forward at the other precisions / configurations BASELINE.json and the reference name:
-                  fp16 operands (the reference's shipped low-precision mode), ref_split (fp16 encoder + fp32 heads: the
-                  reference's exact precision split, mickey_extractor.py:49-56), vit_small (the encoder north_star names),
-                  config5 (1280x720, Sinkhorn matcher, fp16); each a full timed run with its own dominant-stage roofline
-  sustained    -- the headline configuration again over 60 steps (clocks settled at the socket power limit)
+                  cores on a bounded sample (1 pair; 1 warm-up + best of 2), N = 1 only
+  value_ref_precision -- the same forward at the reference's literal precision split (fp16 ViT + fp32-grade heads,
+                  mickey_extractor.py:49-56; leg `ref_split`), pairs/s
+  single_pair_ms -- BASELINE.json configs[1]: one 540x720 pair, hipGraph replay
+Everything else -- the full per-stage roofline list, every leg (--legs all: fp16 everywhere, ref_split, ref_split_fp32mfma,
+attn_mfma16, vit_small, config5), --sustained (60 steps), --include-h2d (PCIe-inclusive), --precision (errors vs the oracle
+outputs of the same run) -- goes to gpurun_out/bench_detail.json (--detail PATH) and is summarised on stderr.
 """
 import argparse
 import json
@@ -257,16 +257,16 @@ def cpu_baseline(cfg, sd):
         return t
 
     one(False)   # warm-up (thread pools, allocator, first-touch of the weights)
-    runs = [one(True) for _ in range(3)]
-    med = {k: sorted(r[k] for r in runs)[1] for k in runs[0]}
+    runs = [one(True) for _ in range(2)]
+    med = min(runs, key=lambda r: r["total"])   # the faster of the two: the baseline gets its best shot
     return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
             "kind_note": "the oracle restatement, not the reference module itself: /root/reference does not exist on the GPU box; "
                          "threads capped at 32 because torch-CPU gets slower beyond that on these ops",
             "pinned_by": "tests/test_oracle_golden.py (the oracle vs the reference's own outputs, tests/golden/*.npz, regenerated "
                          "from /root/reference by oracle/make_golden.py in test_committed_fixtures_reproduce_from_the_reference)",
-            "protocol": "1 warm-up + median of 3", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
+            "protocol": "1 warm-up + best of 2", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
             "sample": "1 pair 540x720, full forward (ViT-L fp32 + heads + dual-softmax + 20x100 RANSAC), torch-CPU "
-                      "oracle, median %.2f s per pair" % med["total"]}
+                      "oracle, %.2f s per pair (1 warm-up + best of 2)" % med["total"]}
 
 
 def precision_report(make_model, syn, dev, args, oracle_out):
@@ -335,17 +335,20 @@ def parse_args(argv=None):
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the fp16 / ref_split legs")
-    ap.add_argument("--no-legs", action="store_true", help="skip the vit_small and config5 legs")
-    ap.add_argument("--legs", default=None, help="dev: comma-separated subset of the legs to run (fp16, ref_split, ref_split_fp32mfma, attn_mfma16, vit_small, config5)")
-    ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step sustained leg")
-    ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no sustained / PCIe / "
-                                                         "single-pair / CPU legs (profiling passes)")
-    ap.add_argument("--include-h2d", action="store_true", default=True,
-                    help="also report the PCIe-inclusive rate under 'pcie_inclusive' (default at N=1): uint8 frames from host "
+    ap.add_argument("--legs", default="ref_split",
+                    help="comma-separated extra legs, each a full timed run written to the detail file: fp16, ref_split, "
+                         "ref_split_fp32mfma, attn_mfma16, vit_small, config5; 'all'; 'none'.  Default: ref_split only (the "
+                         "reference's literal precision split, reported in the line as value_ref_precision)")
+    ap.add_argument("--sustained", action="store_true", help="also run the headline configuration over 60 steps (detail file)")
+    ap.add_argument("--precision", action="store_true",
+                    help="also report every feature output's error vs the CPU oracle outputs of this run (detail file)")
+    ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no single-pair / CPU legs "
+                                                         "(profiling passes)")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="also report the PCIe-inclusive rate under 'pcie_inclusive' (detail file): uint8 frames from host "
                          "memory through the input pipeline (pinned ring, H2D, resize kernel) into the forward; never `value`")
-    ap.add_argument("--no-h2d", dest="include_h2d", action="store_false", help="skip the PCIe-inclusive leg")
-    ap.add_argument("--no-single", action="store_true", help="skip the one-pair latency leg reported under 'single_pair'")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-pair latency leg reported as 'single_pair_ms'")
+    ap.add_argument("--detail", default=None, help="path of the detail JSON (default gpurun_out/bench_detail.json; 'none' = do not write)")
     ap.add_argument("--no-ln-fold", action="store_true", help="dev: stand-alone LayerNorm kernels instead of the folded form (A/B)")
     ap.add_argument("--no-half-rows", action="store_true", help="dev: never pick the 64x128 GEMM tiling automatically (A/B)")
     ap.add_argument("--gemm-tile", type=int, default=0, help="dev: mk_gemm_set_tile mode (0 = automatic)")
@@ -361,8 +364,14 @@ def parse_args(argv=None):
                          "the printed line is marked \"stub\": true and is not a measurement")
     args = ap.parse_args(argv)
     if args.lean:
-        args.no_alt = args.no_legs = args.no_sustained = args.no_single = args.no_cpu_baseline = True
-        args.include_h2d = False
+        args.no_single = args.no_cpu_baseline = True
+        args.include_h2d = args.sustained = args.precision = False
+        args.legs = "none"
+    all_legs = ("fp16", "ref_split", "ref_split_fp32mfma", "attn_mfma16", "vit_small", "config5")
+    args.leg_set = set(all_legs) if args.legs == "all" else set() if args.legs in ("none", "") else set(args.legs.split(","))
+    unknown = args.leg_set - set(all_legs)
+    if unknown:
+        ap.error("unknown leg(s) %s; known: %s" % (sorted(unknown), ", ".join(all_legs)))
     return args
 
 
@@ -467,15 +476,21 @@ def per_rank_ms(steps):
     return {"min": min(ms), "max": max(ms), "all": [round(m, 3) for m in ms]} if ms else None
 
 
-def place_rank(args, rank, world, use_dist):
-    """N > 1: pin every rank to its GPU's NUMA cores (or an even split of the allowed cores), mickey_amd.distributed.pin_rank;
-    returns the list of all ranks' placements on rank 0 (None elsewhere / at N = 1 / with --no-pin)."""
-    import torch.distributed as dist
+def pin_this_rank(args, rank, world, use_dist):
+    """N > 1, BEFORE init_process_group (the RCCL proxy threads inherit the mask): pin this rank to its GPU's NUMA cores (or
+    an even split of the allowed cores), mickey_amd.distributed.pin_rank.  -> this rank's placement or None."""
     from mickey_amd import distributed as D
     if not use_dist or args.no_pin:
         return None
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    mine = D.pin_rank(int(os.environ.get("LOCAL_RANK", rank)), local_world)
+    return D.pin_rank(int(os.environ.get("LOCAL_RANK", rank)), local_world)
+
+
+def gather_placements(mine, rank, world):
+    """After init_process_group: the list of all ranks' placements on rank 0 (None elsewhere / when nothing was pinned)."""
+    import torch.distributed as dist
+    if mine is None:
+        return None
     every = [None] * world
     dist.all_gather_object(every, mine)
     return every if rank == 0 else None
@@ -488,9 +503,11 @@ def main_stub(args, rank, world, use_dist):
     from mickey_amd import distributed as D
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    mine = pin_this_rank(args, rank, world, use_dist)
+    if use_dist:
         dist.init_process_group(args.backend if args.backend != "nccl" else "gloo", rank=rank, world_size=world)
         world = dist.get_world_size()
-    affinity = place_rank(args, rank, world, use_dist)
+    affinity = gather_placements(mine, rank, world)
     B = args.batch
     g = torch.Generator().manual_seed(1234 + 2 * rank)
     data0 = {"image0": torch.rand((B, 3, 8, 8), generator=g), "image1": torch.rand((B, 3, 8, 8), generator=g)}
@@ -505,7 +522,8 @@ def main_stub(args, rank, world, use_dist):
                           "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
                           "per_rank_ms_per_step": per_rank_ms(args.steps),
-                          "config": {"pairs_per_gpu": B, "global_batch": world * B, "affinity": affinity}}), flush=True)
+                          "config": {"pairs_per_gpu": B, "global_batch": world * B, "affinity": affinity}},
+                         separators=(",", ":")), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -558,11 +576,12 @@ def main(argv=None):
         return main_stub(args, rank, world, use_dist)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    mine = pin_this_rank(args, rank, world, use_dist)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()   # what RCCL actually saw
-    affinity = place_rank(args, rank, world, use_dist)
+    affinity = gather_placements(mine, rank, world)
 
     from mickey_amd import distributed as D
     from mickey_amd import ops, synthetic as syn
@@ -606,11 +625,12 @@ def main(argv=None):
     ev_steps = args.steps
     if graphed and prof is not None:
         # a replayed graph bypasses the Python-level launch wrappers: time the launches of ONE extra eager step
-        model.graph_mode = False
+        mode_was, model.graph_mode = model.graph_mode, False
         prof.on = True
         model(dict(data0))
         torch.cuda.synchronize()
         prof.on = False
+        model.graph_mode = mode_was
         ev_steps = 1
     if use_dist:
         assert poses is not None and poses[0].shape[0] == world * B, "gathered poses do not cover the global batch"
@@ -645,7 +665,7 @@ def main(argv=None):
         }
 
     single = rank == 0 and not use_dist
-    if single and not args.no_sustained:
+    if single and args.sustained:
         # the headline configuration over 60 steps: the part runs at its socket power limit and the clock it sustains
         # settles below what a 20-step region sees (round 1: -3 %)
         a3 = argparse.Namespace(**vars(args))
@@ -653,13 +673,30 @@ def main(argv=None):
         dts, _, _ = measure(model, data0, a3, False, 1, None, None)
         out["sustained"] = {"value": B * a3.steps / dts, "unit": "pairs/s", "steps": a3.steps, "ms_per_step": dts / a3.steps * 1e3,
                             "what": "same model / batch / dtype, 60 back-to-back steps straight after the timed region"}
+    if single and not args.no_single and B != 1:
+        # BASELINE.json configs[1]: ONE 540x720 pair (latency; the forward is replayed as a hipGraph when AMD.GRAPH allows)
+        d1 = {k: v.to(dev) for k, v in syn.synthetic_batch(B=1, H=H, W=W, seed=99).items()}
+        a1 = argparse.Namespace(**vars(args))
+        a1.steps, a1.warmup = 20, 5
+        try:
+            dt1, _, _ = measure(model, d1, a1, False, 1, None, None)
+            out["single_pair"] = {"value": a1.steps / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / a1.steps * 1e3, "steps": a1.steps,
+                                  "hip_graph": len(model._graphs) > 0, "what": "BASELINE.json configs[1]: batch of one pair, same model"}
+        except Exception as e:   # extra information: must not cost the headline line
+            out["single_pair"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if single and args.include_h2d:
+        from mickey_amd import input_pipeline as ip
+        try:
+            out["pcie_inclusive"] = ip.bench_h2d(model, B, H, W, steps=max(2, min(args.steps, 3)))
+        except Exception as e:
+            out["pcie_inclusive"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     del model
     torch.cuda.empty_cache()
 
     def leg(name, what, dtype, steps, warmup, batch_pairs=None, hw=(H, W), dominant="encoder_gemm", **mk):
         """One more full timed run (same measure(): barrier-free at N = 1, synchronize on both sides) of another
-        precision / configuration, with its own per-stage roofline list."""
-        if args.legs is not None and name not in args.legs.split(","):
+        precision / configuration, with its own per-stage roofline list (detail file)."""
+        if not single or name not in args.leg_set:
             return
         try:
             _leg(name, what, dtype, steps, warmup, batch_pairs, hw, dominant, **mk)
@@ -680,7 +717,8 @@ def main(argv=None):
         if prof is not None:
             prof.records = []
         dtl, lastl, _ = measure(m, d, a, False, 1, None, prof)
-        ent = {"what": what, "dtype": dtype, "value": bp * steps / dtl, "unit": "pairs/s", "steps": steps, "warmup": warmup,
+        ent = {"what": what, "dtype": dtype, "heads_operands": str(m.heads_dtype).replace("torch.", ""),
+               "value": bp * steps / dtl, "unit": "pairs/s", "steps": steps, "warmup": warmup,
                "ms_per_step": dtl / steps * 1e3, "pairs_per_step": bp, "image_hw": list(hw),
                "finite_output": bool(torch.isfinite(lastl["R"]).all())}
         if prof is not None and prof.records and not len(m._graphs):
@@ -696,48 +734,22 @@ def main(argv=None):
             ops.attn_set_mode(args.attn_mode)
         out.setdefault("legs", {})[name] = ent
 
-    if single and not args.no_alt and args.dtype == "bf16":
-        leg("fp16", "fp16 operands everywhere: the reference's shipped low-precision mode for the encoder "
-            "(MICKEY.DINOV2.FLOAT16), heads in fp16 too", "fp16", args.steps, args.warmup)
-        leg("ref_split", "the reference's precision split (mickey_extractor.py:49-56): fp16 encoder + fp32 heads, the heads' 3x3 "
-            "convolutions on split fp16 operands (hi + lo planes, three MFMA sweeps: fp32-grade products; AMD.HEADS_DTYPE: split)",
-            "fp16", max(5, args.steps // 2), 2, heads="split")
-        leg("ref_split_fp32mfma", "the same split with the heads on the exact fp32-input MFMA (AMD.HEADS_DTYPE: fp32; round 3's "
-            "ref_split)", "fp16", 3, 1, heads="fp32")
-        if "value" in out.get("legs", {}).get("fp16", {}):
-            out["alt"] = {"dtype": "fp16", "value": out["legs"]["fp16"]["value"], "unit": "pairs/s", "steps": args.steps,
-                          "note": "= legs.fp16 (kept for readers of the round-2 line)"}
-    if single and not args.no_legs:
-        leg("attn_mfma16", "the headline configuration with the attention kernel on v_mfma_f32_16x16x32 (mk_attn_set_mode 5; the "
-            "cheaper shape per flop at the power limit, LABNOTES R4.11 / R4.13).  Not the default: a single pair is 12-17 %% "
-            "slower with it, and ONE kernel family has to serve every batch size for a pair's result not to depend on its batch",
-            args.dtype, args.steps, args.warmup, dominant="attention", attn_mode=5)
-        leg("vit_small", "DINOv2 ViT-S/14 encoder (the size north_star names; 305 GFLOP per pair, attention 46 %% of it) "
-            "+ the same heads / matcher / solver, %d pairs of 540x720" % B, args.dtype, max(5, args.steps // 2), 2,
-            arch="vit_small", dominant="attention")
-        leg("config5", "BASELINE.json configs[4]: 8 pairs of 1280x720 (51x91 grid, n = 4641), Sinkhorn matcher (10 "
-            "iterations; governed by HBM: 20 LSE passes over the (n+1)^2 fp32 coupling matrix = 301 MB per pair at 540x720, "
-            "1.72 GB here), fp16 operands", "fp16", 3, 1, batch_pairs=8, hw=(720, 1280), dominant="matcher", matcher="Sinkhorn")
-    if single and (args.include_h2d or not args.no_single):
-        m2 = make_model(args.dtype)[0]
-        if args.include_h2d:
-            from mickey_amd import input_pipeline as ip
-            try:
-                out["pcie_inclusive"] = ip.bench_h2d(m2, B, H, W, steps=max(2, min(args.steps, 3)))
-            except Exception as e:   # extra information: must not cost the headline line
-                out["pcie_inclusive"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        if not args.no_single and B != 1:
-            # BASELINE.json configs[1]: ONE 540x720 pair (latency; the forward is replayed as a hipGraph when AMD.GRAPH allows)
-            d1 = {k: v.to(dev) for k, v in syn.synthetic_batch(B=1, H=H, W=W, seed=99).items()}
-            a1 = argparse.Namespace(**vars(args))
-            a1.steps, a1.warmup = 20, 5
-            try:
-                dt1, _, _ = measure(m2, d1, a1, False, 1, None, None)
-                out["single_pair"] = {"value": a1.steps / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / a1.steps * 1e3, "steps": a1.steps,
-                                      "hip_graph": len(m2._graphs) > 0, "what": "BASELINE.json configs[1]: batch of one pair, same model"}
-            except Exception as e:
-                out["single_pair"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        del m2
+    leg("ref_split", "PRECISION-MATCHED: the reference's literal precision split (mickey_extractor.py:49-56): fp16 encoder + fp32 "
+        "heads, the heads' 3x3 convolutions and linears on split fp16 operands (hi + lo planes: fp32-grade products; "
+        "AMD.HEADS_DTYPE: split)", "fp16", max(5, args.steps // 2), 2, heads="split")
+    leg("fp16", "fp16 operands EVERYWHERE (encoder as the reference's MICKEY.DINOV2.FLOAT16 mode, and the heads in fp16 too: "
+        "less precise in the heads than the reference's split)", "fp16", args.steps, args.warmup)
+    leg("ref_split_fp32mfma", "the reference's split with the heads on the exact fp32-input MFMA (AMD.HEADS_DTYPE: fp32; round 3's "
+        "ref_split)", "fp16", 3, 1, heads="fp32")
+    leg("attn_mfma16", "the headline configuration with the attention kernel on v_mfma_f32_16x16x32 (mk_attn_set_mode 5; LABNOTES "
+        "R4.11 / R4.13)", args.dtype, args.steps, args.warmup, dominant="attention", attn_mode=5)
+    leg("vit_small", "DINOv2 ViT-S/14 encoder (the size north_star names; 305 GFLOP per pair, attention 46 %% of it) "
+        "+ the same heads / matcher / solver, %d pairs of 540x720" % B, args.dtype, max(5, args.steps // 2), 2,
+        arch="vit_small", dominant="attention")
+    leg("config5", "BASELINE.json configs[4]: 8 pairs of 1280x720 (51x91 grid, n = 4641), Sinkhorn matcher (10 "
+        "iterations; governed by HBM: 20 LSE passes over the (n+1)^2 fp32 coupling matrix = 301 MB per pair at 540x720, "
+        "1.72 GB here), fp16 operands", "fp16", 3, 1, batch_pairs=8, hw=(720, 1280), dominant="matcher", matcher="Sinkhorn")
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -745,27 +757,91 @@ def main(argv=None):
             except Exception as e:   # the line must still be printed (the contract's required keys stay present)
                 out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed",
                                        "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-            # precision of the timed configurations against the oracle outputs of THIS run (the pair the CPU leg just computed)
-            try:
-                out["precision"] = precision_report(make_model, syn, dev, args, cpu_baseline.last_outputs)
-                fl = out["precision"].get("fp16")
-                if fl and "fp16" in out.get("legs", {}):
-                    leg16 = out["legs"]["fp16"]
-                    out["precision_matched"] = {
-                        "what": "the precision-matched number: fp16 operands (the reference ships an fp16 encoder, "
-                                "MICKEY.DINOV2.FLOAT16: True) -- every output lies inside the reference's OWN fp16-vs-fp32 noise "
-                                "floor; = legs.fp16",
-                        "dtype": "fp16", "value": leg16["value"], "unit": "pairs/s", "ms_per_step": leg16["ms_per_step"],
-                        "stages": leg16.get("stages"), "error_vs_oracle": fl["error_vs_oracle"],
-                        "reference_fp16_floor": fl.get("floor"), "inside_floor": fl.get("inside_floor")}
-            except Exception as e:   # a reporting leg must not lose the measured line
-                out["precision"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if args.precision and getattr(cpu_baseline, "last_outputs", None):
+                # precision of the timed configurations against the oracle outputs of THIS run (the pair the CPU leg just computed)
+                try:
+                    out["precision"] = precision_report(make_model, syn, dev, args, cpu_baseline.last_outputs)
+                except Exception as e:   # a reporting leg must not lose the measured line
+                    out["precision"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 3072   # bytes; the driver parses the LAST stdout line out of an 8-KB tail (round 4's 21-KB line was cut: unparsed)
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line rank 0 prints: the contract's keys + roofline + cpu_baseline + a <= 6-entry stage summary.  Pure function
+    of the detail dict (unit-tested on CPU, tests/test_bench_cpu.py)."""
+    def r4(x):
+        return None if x is None else (round(x, 4) if isinstance(x, float) else x)
+
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = r4(line["value"]), r4(line["ms_per_step"])
+    if out.get("stub"):
+        line["stub"] = True
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "pairs_per_gpu", "global_batch", "image_hw", "hypotheses", "heads_operands",
+                                          "parallelism", "hip_graph") if k in cfg}
+    roof = out.get("roofline")
+    if roof:
+        line["roofline"] = {k: r4(roof.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                         "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "traffic_source")}
+        st = sorted(roof.get("stages") or [], key=lambda s: -s["ms_per_step"])[:6]
+        line["stages"] = [{"stage": s["stage"], "ms_per_step": r4(s["ms_per_step"]), "frac": r4(s.get("frac"))} for s in st]
+    else:
+        line["roofline"] = None
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = ({k: r4(cb.get(k)) for k in ("value", "unit", "cores", "cores_available", "kind", "sample") if k in cb}
+                            if cb else None)
+    rs = (out.get("legs") or {}).get("ref_split") or {}
+    if "value" in rs:
+        line["value_ref_precision"] = r4(rs["value"])
+        line["ref_precision"] = "fp16 ViT + fp32-grade heads (the reference's split, mickey_extractor.py:49-56)"
+    sp = out.get("single_pair") or {}
+    if "ms_per_pair" in sp:
+        line["single_pair_ms"] = r4(sp["ms_per_pair"])
+    pr = out.get("per_rank_ms_per_step")
+    if pr and out.get("n_gpus", 1) > 1:
+        line["per_rank_ms_per_step"] = {"min": r4(pr["min"]), "max": r4(pr["max"])}
+    line["finite_output"] = out.get("finite_output")
+    if detail_path:
+        line["detail"] = detail_path
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= LINE_LIMIT:   # cannot happen with the keys above; keep the contract's keys whatever else was added
+        for k in ("stages", "ref_precision", "detail"):
+            line.pop(k, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) < LINE_LIMIT, len(txt)
+    return txt
+
+
+def emit(out, args):
+    """Detail -> file (+ a short summary on stderr); the compact line -> stdout, last."""
+    path = None
+    if args.detail != "none":
+        path = args.detail or os.path.join("gpurun_out", "bench_detail.json")
+        try:
+            full = path if os.path.isabs(path) else os.path.join(ROOT, path)
+            os.makedirs(os.path.dirname(full) or ".", exist_ok=True)
+            with open(full, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            sys.stderr.write("bench.py: detail file not written (%s)\n" % e)
+            path = None
+    for name, ent in (out.get("legs") or {}).items():
+        sys.stderr.write("bench.py leg %-20s %s\n" % (name, "%.1f pairs/s, %.2f ms/step" % (ent["value"], ent["ms_per_step"])
+                                                      if "value" in ent else ent.get("error")))
+    for st in ((out.get("roofline") or {}).get("stages") or []):
+        sys.stderr.write("bench.py stage %-18s %8.3f ms/step  frac %s\n" % (st["stage"], st["ms_per_step"],
+                                                                          "%.3f" % st["frac"] if st.get("frac") is not None else "-"))
+    sys.stderr.flush()
+    print(compact_line(out, path), flush=True)
 
 
 if __name__ == "__main__":

@@ -45,8 +45,9 @@ const char* mk_last_error(void);
  * (lib/datasets/utils.py:61-78; same in demo_inference.py:12-29) for n frames at once.
  *   src  uint8 [n, Hs, Ws, 3] RGB on the device, frame stride stride_img bytes (>= Hs*Ws*3)
  *   dst  fp32  [n, 3, H, W] in [0, 1]
- * Bilinear, half-pixel centres, edge clamp (cv2 INTER_LINEAR sampling, fp32 weights); Hs == H and Ws == W is the
- * identity resize and gives exactly float(v) / 255. */
+ * cv2.resize(uint8, INTER_LINEAR) exactly as OpenCV 4.8.0 computes it: half-pixel centres, edge clamp, 11-bit fixed-point
+ * weights (INTER_RESIZE_COEF_BITS) and its rounding of the two passes, the area-fast path for exact 2x decimation; byte-equal to
+ * oracle/input_oracle.py.  Hs == H and Ws == W is the identity resize and gives exactly float(v) / 255. */
 int mk_preprocess_u8(const unsigned char* src, long long stride_img, int n, int Hs, int Ws, float* dst, int H, int W,
                      mk_stream_t stream);
 

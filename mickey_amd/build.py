@@ -30,7 +30,6 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fno-trapping-math", "-fno-slp-vectorize"] +
                (["-DMK_ATTN_ABLATIONS"] if os.environ.get("MK_ATTN_ABLATIONS") else []) +
                (["-DMK_ATTN_LP_DBG"] if os.environ.get("MK_ATTN_LP_DBG") else []),
-               "mk_matcher.hip": (["-DMK_MATCHER_ALIGN_PROBE"] if os.environ.get("MK_MATCHER_ALIGN_PROBE") else []),
                "mk_input.hip": ["-ffp-contract=off"],   # cv2-exact coordinates: (d + 0.5) * scale - 0.5 must not become an fma
                # the ping-pong GEMM's epilogues are VALU-bound (both waves of a SIMD drain while the matrix pipe idles): SLP packs the
                # (sum, sum of squares) pairs of the row statistics into v_pk_add_f32, which keeps the DPP steps of their 16-lane
@@ -43,16 +42,21 @@ EXTRA_FLAGS = {"mk_attention.hip": ["-fno-honor-nans", "-fno-signed-zeros", "-fn
 
 
 USAGE_JSON = os.path.join(OBJDIR, "resource_usage.json")
+FLAGS_JSON = os.path.join(OBJDIR, "object_flags.json")   # {object: the flags it was built with}: part of the staleness check
 _REMARK = re.compile(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|"
                      r"Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|Dynamic Stack):\s+(\S+)")
 
 
-def _load_usage():
+def _load_json(path):
     try:
-        with open(USAGE_JSON) as f:
+        with open(path) as f:
             return json.load(f)
     except (OSError, ValueError):
         return {}
+
+
+def _load_usage():
+    return _load_json(USAGE_JSON)
 
 
 def _parse_resource_remarks(out):
@@ -128,10 +132,16 @@ def build(force=False, save_temps=False, verbose=True):
              "-I", INCLUDE]
     jobs = []
     objs = []
+    # an object is stale when a source / header is newer OR when it was built with other flags (probe builds driven by
+    # environment variables -- MK_LN_ABL, MK_ATTN_ABLATIONS ... -- must not survive into the next plain build)
+    built_with = _load_json(FLAGS_JSON)
     for s in srcs:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+        fl = " ".join(flags + EXTRA_FLAGS.get(os.path.basename(s), []))
+        if (force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time)
+                or built_with.get(os.path.basename(o)) != fl):
+            built_with[os.path.basename(o)] = fl
             cmd = [cc] + flags + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
@@ -159,7 +169,10 @@ def build(force=False, save_temps=False, verbose=True):
         with open(USAGE_JSON, "w") as f:
             json.dump(usage, f, indent=1, sort_keys=True)
     if failed:
-        raise RuntimeError("hipcc failed")
+        raise RuntimeError("hipcc failed")   # (FLAGS_JSON not updated: the failed objects stay stale)
+    if jobs:
+        with open(FLAGS_JSON, "w") as f:
+            json.dump(built_with, f, indent=1, sort_keys=True)
     lib = lib_path()
     if jobs or not os.path.exists(lib) or os.path.getmtime(lib) < _newest(objs):
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs

@@ -2,15 +2,16 @@
 //
 // dual-softmax (feature_matcher.py:64-83):  S = dsc0^T dsc1 / T, a learned scalar dustbin appended as
 // last row / column / corner, P = softmax_rows(S+) * softmax_cols(S+), cropped back to n0 x n1.
-//
-// The N x M x C correlation runs on the EXACT-fp32 matrix core path (v_mfma_f32_32x32x2_f32, bitwise
-// an fp32 fma chain), because `final_scores` feeds a sampler and must match the fp32 reference to
-// round-off.  The (n0+1) x (n1+1) coupling matrix is never materialised:
-//   pass 1  ONE correlation: online (max, sum) partials of the rows of S (per column chunk) and of its columns (per
-//           32-row block) from the same register-resident tile; the scaled correlation is stored;
-//   merge   partials (+ dustbin term) -> log2-sum-exp vectors of both directions;
-//   pass 2  element-wise: scores = 2^((v - lse_col) + (v - lse_row)), kp_scores = scr0 (x) scr1,
-//           final_scores = scores * kp_scores (each optional), in place over the stored correlation where possible.
+// `final_scores` feeds a sampler and must match the fp32 reference to round-off; the (n0+1) x (n1+1) coupling
+// matrix is never materialised.  Two correlation paths (AMD.MATCHER_CORR):
+//   split (default for L2-normalised descriptors)  descriptors as split-fp16 planes (hi + lo, fp32-grade products on the
+//           16-bit matrix cores); pass 1 = correlation -> maximum-free row / column sums only (lse_split_kernel); merge
+//           (lse_final_kernel); pass 2 = the SAME correlation again -> scores / kp_scores / final_scores from registers
+//           through LDS (dual_softmax_split_apply_kernel).  No stored correlation.
+//   exact   v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain) for descriptors of any norm: pass 1 stores the scaled
+//           correlation and online (max, sum) partials (lse_partial_kernel), pass 2 is element-wise, in place
+//           (dual_softmax_apply_kernel).
+// Sinkhorn (feature_matcher.py:93-137) and mutual-NN (:19-46) follow below.
 #include <type_traits>
 
 #include "mk_common.hpp"

@@ -181,8 +181,10 @@ def gpu_numa_cpus(device_index):
 
 
 def pin_rank(local_rank, local_world):
-    """Pin this process (os.sched_setaffinity) as affinity_plan says and size torch's intra-op pool to the set.
-    Returns what was done, for the bench line: {'numa_node', 'cpus', 'n_cpus'} or {'error': ...}."""
+    """Pin this process as affinity_plan says and size torch's intra-op pool to the set.  sched_setaffinity(0, ...) moves
+    only the calling thread and is inherited by threads created AFTERWARDS, so call this before init_process_group (RCCL
+    proxy threads) where possible; threads that already exist (HIP runtime, torch pools) are moved one by one through
+    /proc/self/task.  Returns what was done: {'numa_node', 'cpus', 'n_cpus', 'threads_pinned', 'threads_seen'} or {'error': ...}."""
     import os
     try:
         avail = sorted(os.sched_getaffinity(0))
@@ -194,8 +196,20 @@ def pin_rank(local_rank, local_world):
             peers = (same.index(local_rank), len(same))
         cpus = affinity_plan(local_rank, local_world, avail, ncpus, peers)
         os.sched_setaffinity(0, cpus)
+        seen = pinned = 0
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = []
+        for tid in tids:
+            seen += 1
+            try:
+                os.sched_setaffinity(tid, cpus)
+                pinned += 1
+            except OSError:   # the thread ended meanwhile
+                pass
         torch.set_num_threads(max(1, min(len(cpus), 16)))
         return {"numa_node": node, "cpus": "%d-%d" % (cpus[0], cpus[-1]) if cpus == list(range(cpus[0], cpus[-1] + 1)) else cpus,
-                "n_cpus": len(cpus)}
+                "n_cpus": len(cpus), "threads_pinned": pinned, "threads_seen": seen}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -301,11 +301,8 @@ class MickeyRelativePose(nn.Module):
         return sol["R"], sol["t"], sol["inliers"]
 
     def _forward_eager(self, data, return_inliers=False):
-        try:
-            self.compute_correspondences(data)
-            res = self.estimate_pose(data, return_inliers)
-        except _native.MickeyHipError:
-            raise  # a missing / failing HIP library is never papered over
+        self.compute_correspondences(data)   # a missing / failing HIP library raises _native.MickeyHipError: never papered over
+        res = self.estimate_pose(data, return_inliers)
         if return_inliers:
             data["inliers_list"] = res[3]
         data["R"], data["t"], data["inliers"] = res[0], res[1], res[2]

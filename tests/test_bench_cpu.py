@@ -94,3 +94,48 @@ def test_real_bench_refuses_more_gpus_than_visible():
     if torch.cuda.device_count() >= 2:
         pytest.skip("2 GPUs visible here")
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_compact_line_from_the_round4_detail_is_small_and_complete():
+    """Round 4's line was 21 KB and the driver (8-KB tail) could not parse it.  The line is now a pure function of the detail
+    dict: fed with that very 21-KB object (profiles/r04_bench_b32.json) it must come out < 3 KB, parse, and carry the
+    contract's keys, the dominant-kernel roofline, the CPU baseline and a <= 6-entry stage summary."""
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_b32.json")))
+    assert len(json.dumps(detail)) > 8192                      # the input really is the oversized one
+    txt = bench.compact_line(detail, "gpurun_out/bench_detail.json")
+    assert "\n" not in txt and len(txt) < bench.LINE_LIMIT <= 3072
+    line = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(detail["value"], rel=1e-3) and line["ms_per_step"] == pytest.approx(detail["ms_per_step"], rel=1e-3)
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+              "launches", "traffic_source"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-3)
+    for k in ("value", "unit", "cores", "cores_available", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert 1 <= len(line["stages"]) <= 6 and all(set(s) == {"stage", "ms_per_step", "frac"} for s in line["stages"])
+    assert line["stages"][0]["stage"] == "encoder_gemm"        # sorted by time
+    assert line["config"]["workload"] and "affinity" not in line["config"]
+    assert line["value_ref_precision"] == pytest.approx(detail["legs"]["ref_split"]["value"], rel=1e-3)
+    assert line["single_pair_ms"] == pytest.approx(detail["single_pair"]["ms_per_pair"], rel=1e-3)
+    assert "legs" not in line and "precision" not in line and "alt" not in line and "precision_matched" not in line
+
+
+def test_stub_line_is_last_and_small():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 3072 and json.loads(last)["n_gpus"] == 2
+
+
+def test_default_arguments_keep_the_driver_run_short():
+    """The default run = headline + ref_split leg + one-pair leg + CPU baseline; everything else is opt-in."""
+    a = bench.parse_args([])
+    assert a.leg_set == {"ref_split"} and not a.sustained and not a.include_h2d and not a.precision
+    assert bench.parse_args(["--legs", "all"]).leg_set >= {"fp16", "ref_split", "vit_small", "config5"}
+    lean = bench.parse_args(["--lean"])
+    assert lean.leg_set == set() and lean.no_cpu_baseline and lean.no_single
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--legs", "nonsense"])

@@ -162,7 +162,11 @@ def test_no_product_kernel_spills_registers():
     for src, kernels in usage.items():
         for k in kernels:
             seen += 1
-            # (SGPR spills go to spare VGPR lanes, not to memory: several kernels have a few, they are not asserted on)
+            # SGPR spills go to spare VGPR lanes (v_writelane), not to memory: a few dozen in cold kernels are tolerated; the one
+            # large case is named -- lse_partial_kernel<false>, the exact-fp32 matcher for descriptor widths != 128 (its 64
+            # operand registers per side leave the scalar unit no VGPR-free bookkeeping): not on the benchmarked path
+            allowed = 400 if "lse_partial_kernelILb0E" in k["name"] else 64
+            assert k.get("sgpr_spill", 0) <= allowed, (src, k)
             assert k.get("vgpr_spill", 0) == 0, (src, k)
             # no private memory at all (round 3 had 32 B / lane in every GEMM kernel: SROA kept a 16-byte slice of the by-value
             # GemmParams -- qscale | pos | npatch -- as an alloca because `f32x4 *= p.qscale` loaded it as <1 x float>)

@@ -97,7 +97,8 @@ def test_full_forward_golden(golden, cfg, dtype, heads):
     if model.lp_dtype != torch.float32:   # pixels, the largest of 364 keypoints: not beyond what the oracle-side 16-bit evaluation moves one
         kp_floor = float(golden("noise_floor_lp")["%s_182_kps0_maxabs" % FLOOR_OF[model.lp_dtype]])
         assert kp_max <= kp_floor, (kp_max, kp_floor)
-    assert kp_max < 0.2, kp_max
+    else:                                 # fp32 parity mode: rounding only (coordinates up to ~200 px in fp32)
+        assert kp_max <= 5e-3, kp_max
     # contract: shapes / keys the reference's callers read
     assert R.shape == (2, 3, 3) and t.shape == (2, 1, 3) and data["inliers"].shape == (2, 1)
     assert data["kps0_shape"] == [13, 14] and data["depth0_map"].shape == (2, 1, 13, 14) and data["down_factor"] == 14
