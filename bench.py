@@ -717,7 +717,8 @@ def main(argv=None):
         if prof is not None:
             prof.records = []
         dtl, lastl, _ = measure(m, d, a, False, 1, None, prof)
-        ent = {"what": what, "dtype": dtype, "heads_operands": str(m.heads_dtype).replace("torch.", ""),
+        ent = {"what": what, "dtype": dtype,
+               "heads_operands": "float32 as split fp16 planes" if m.heads_split else str(m.heads_dtype).replace("torch.", ""),
                "value": bp * steps / dtl, "unit": "pairs/s", "steps": steps, "warmup": warmup,
                "ms_per_step": dtl / steps * 1e3, "pairs_per_step": bp, "image_hw": list(hw),
                "finite_output": bool(torch.isfinite(lastl["R"]).all())}

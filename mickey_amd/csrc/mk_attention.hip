@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float shift = first ? mx : fmaxf(mx, 0.f);     // never lower m after the first tile (rows that did not outgrow
                                                              // it: shift 0, bit-identical to not re-basing)
-        const float alpha = __builtin_amdgcn_exp2f(-shift);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-shift);   // first tile: O = l = 0 (2^-shift may be +inf there: 0 x inf)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           o[qb][0][i] *= alpha;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold16_kernel(c
           mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           const float shift = first ? mx : fmaxf(mx, 0.f);
-          const float alpha = __builtin_amdgcn_exp2f(-shift);
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-shift);   // first tile: O = l = 0 (2^-shift may be +inf there: 0 x inf)
 #pragma unroll
           for (int b4 = 0; b4 < 4; ++b4)
 #pragma unroll

@@ -75,6 +75,54 @@ def dinov2_state_dict(arch="vit_large", seed=0, prefix="", pos_grid=37):
     return sd
 
 
+OUTLIER_LEVELS = (250.0, -400.0, 520.0, -600.0)
+
+
+def plant_outliers(sd, arch="vit_large", prefix=DINO_PREFIX, seed=0, ln_gain=36.0, qk_gain=3.0):
+    """Give random DINOv2 weights the activation statistics released ViT-L weights are known for (massive activations: a
+    handful of residual channels carrying |x| in the hundreds in every token from an early block on, LayerNorm gains that
+    compensate, a few attention heads with logits of several tens) -- the numerics a 16-bit residual stream, a LayerNorm folded
+    into GEMM epilogues and a softmax without a per-tile maximum have to survive (tests/test_outliers_gpu.py).  In place, and
+    deterministic in (arch, seed):
+      * block `start` = depth // 4 writes OUTLIER_LEVELS into 4 channels of every token (mlp.fc2.bias, ls2.gamma = 1);
+        later blocks add a token-dependent part on top (their fc2 rows x 40, ls2.gamma 0.3): |x| ~ 200 ... 700 there;
+      * from then on the row variance is the outliers' (std ~ 29, the ordinary channels' 0.8): every later LayerNorm (norm1 / norm2 / final norm) gets
+        weight x ln_gain on the ordinary channels and 0.02 on the outlier channels, as trained networks do;
+      * every third block from `start` on, heads 1 and heads - 2 get their q and k rows (weight and bias) x qk_gain:
+        attention logits of +-40 and more in those heads.
+    Returns (channels, start)."""
+    D, depth, heads = VIT_ARCH[arch]
+    g = torch.Generator().manual_seed(3000 + seed)
+    ch = torch.randperm(D, generator=g)[:len(OUTLIER_LEVELS)]
+    start = max(1, depth // 4)
+    level = torch.tensor(OUTLIER_LEVELS)
+    ordinary = torch.ones(D, dtype=torch.bool)
+    ordinary[ch] = False
+
+    def ln(key):
+        w = sd[key + ".weight"]
+        w[ordinary] *= ln_gain
+        w[ch] = 0.02
+    for i in range(start, depth):
+        p = prefix + "blocks.%d." % i
+        if i == start:
+            sd[p + "mlp.fc2.bias"][ch] = level
+            sd[p + "ls2.gamma"][ch] = 1.0
+        else:
+            ln(p + "norm1")
+            sd[p + "mlp.fc2.weight"][ch] *= 40.0
+            sd[p + "ls2.gamma"][ch] = 0.3
+            ln(p + "norm2")
+        if i > start and (i - start) % 3 == 0:
+            for h in (1, heads - 2):
+                for base in (0, D):   # q rows, k rows of attn.qkv
+                    rows = slice(base + h * 64, base + (h + 1) * 64)
+                    sd[p + "attn.qkv.weight"][rows] *= qk_gain
+                    sd[p + "attn.qkv.bias"][rows] *= qk_gain
+    ln(prefix + "norm")
+    return ch, start
+
+
 def _basic_block(g, sd, p, cin, cout):
     sd[p + "conv1.weight"] = _randn(g, (cout, cin, 3, 3), math.sqrt(2.0 / (9 * cin)))
     sd[p + "conv2.weight"] = _randn(g, (cout, cout, 3, 3), math.sqrt(2.0 / (9 * cout)))
@@ -125,10 +173,12 @@ def heads_state_dict(cfg, seed=0, prefix=EXTRACTOR_PREFIX):
     return sd
 
 
-def mickey_state_dict(cfg, seed=0, arch="vit_large", dustbin=1.0):
-    """Full synthetic checkpoint ``state_dict`` (DINOv2 keys included)."""
+def mickey_state_dict(cfg, seed=0, arch="vit_large", dustbin=1.0, outliers=False):
+    """Full synthetic checkpoint ``state_dict`` (DINOv2 keys included).  outliers: plant_outliers() on the encoder."""
     sd = {}
     sd.update(dinov2_state_dict(arch, seed, prefix=DINO_PREFIX))
+    if outliers and not _SHAPES_ONLY:
+        plant_outliers(sd, arch, DINO_PREFIX, seed)
     sd.update(heads_state_dict(cfg, seed))
     if cfg["FEATURE_MATCHER"]["TYPE"] == "DualSoftmax":
         if cfg["FEATURE_MATCHER"]["DUAL_SOFTMAX"]["USE_DUSTBIN"]:

@@ -15,6 +15,9 @@ does (the reference's own low-precision switch is `x.to(amp_dtype)` + a half-pre
     size   "182"  2 pairs of 182 x 196 (the golden case of tests/golden/full_forward.npz)
            "720"  1 pair of 720 x 540  (the Map-free size)
            "vits720"  the same pair through a DINOv2 ViT-S/14 encoder (the size BASELINE.json's north_star names)
+           "out182", "out720"  the 182 / 720 cases with synthetic.plant_outliers() applied to the encoder weights: residual
+                      channels at |x| ~ 600, compensating LayerNorm gains, attention logits of several tens (the statistics of
+                      released DINOv2 ViT-L weights; tests/test_outliers_gpu.py)
     dtype  "bf16", "fp16"
 
 as scalars named  <dtype>_<scope>_<size>_<key> (plus ..._kps0_maxabs: the largest keypoint displacement in pixels).  Where /root/reference exists (the build container) the REFERENCE ITSELF is
@@ -103,7 +106,7 @@ def reference_floors(cfg, sd, batch, size, floor):
     ref_shim.uninstall()
 
 
-def main(out_dir=None, sizes=("182", "720", "vits720")):
+def main(out_dir=None, sizes=("182", "720", "vits720", "out182", "out720")):
     import copy
     torch.set_num_threads(os.cpu_count())
     cfg_l = default_cfg()
@@ -112,13 +115,18 @@ def main(out_dir=None, sizes=("182", "720", "vits720")):
     cfg_s["AMD"]["VIT"] = "vit_small"
     cfg_s["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = 384
     cases = {"182": dict(B=2, H=182, W=196, seed=1234), "720": dict(B=1, H=720, W=540, seed=1234),
-             "vits720": dict(B=1, H=720, W=540, seed=1234)}
+             "vits720": dict(B=1, H=720, W=540, seed=1234), "out182": dict(B=2, H=182, W=196, seed=1234),
+             "out720": dict(B=1, H=720, W=540, seed=1234)}
+    sd_o = None
     floor = {}
     with torch.no_grad():
         for size in sizes:
             batch = syn.synthetic_batch(**cases[size])
             if size == "vits720":
                 cfg, sd, nh = cfg_s, syn.mickey_state_dict(cfg_s, seed=0, arch="vit_small"), 6
+            elif size.startswith("out"):
+                sd_o = sd_o if sd_o is not None else syn.mickey_state_dict(cfg_l, seed=0, outliers=True)
+                cfg, sd, nh = cfg_l, sd_o, 16
             else:
                 cfg, sd, nh = cfg_l, sd_l, 16
             ref = correspondences(sd, cfg, batch, heads=nh)

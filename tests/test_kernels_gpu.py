@@ -479,6 +479,55 @@ def test_flash_attention(dtype, ntok, nimg, heads, mode):
 
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_flash_attention_extreme_logits(dtype, mode):
+    """Logits of several tens and more, as released ViT weights produce in some heads (tests/test_outliers_gpu.py): per query
+    a constant offset c_q (softmax does not see it, the kernel's running maximum does) + key-dependent terms, so that
+      * queries 0-63: every key of the FIRST tile at <= -150 in the log2 domain (2^-m of the first re-base overflows fp32:
+        the accumulators must not be scaled by it), later tiles 200 higher (the re-base path, sums that overflow to +inf);
+      * queries 64-127: the first tile carries the row maximum (+160), everything later is 2^-50 of it and less;
+      * the rest: ordinary rows with spread 30.
+    Every output finite and element-wise equal to an fp64 softmax to the operand type's rounding."""
+    from mickey_amd import ops
+    dev = _dev()
+    ops.attn_set_mode(mode)
+    nimg, heads, ntok = 2, 2, 700
+    pad = (ntok + 63) // 64 * 64
+    gg = g(4242)
+    # q = [a_q, 1, c_q, noise ...], k = [1, b_k, d_k, noise ...]: q.k (log2 domain) = a_q + b_k + c_q d_k + small
+    qn = torch.randn((nimg, heads, ntok, 64), generator=gg) * 0.5
+    kn = torch.randn((nimg, heads, ntok, 64), generator=gg) * 0.5
+    a, b, c, d = torch.zeros(ntok), torch.zeros(ntok), torch.zeros(ntok), torch.zeros(ntok)
+    b[:64] = -90.0
+    b[64:] = 10.0 * torch.randn(ntok - 64, generator=gg).clamp(-3, 3)
+    b[300] = 110.0
+    a[:64] = -60.0                      # queries 0-63: first tile at -150, key 300 at +50
+    c[64:128] = 1.0                     # queries 64-127: first tile at +160, the rest at 0 +- 30, key 300 at +110
+    d[:64] = 250.0
+    qn[..., 0], qn[..., 1], qn[..., 2] = a, 1.0, c
+    kn[..., 0], kn[..., 1], kn[..., 2] = 1.0, b, d
+    q2, k16 = qn.to(dtype), kn.to(dtype)
+    v16 = torch.randn((nimg, heads, ntok, 64), generator=gg).to(dtype)
+    q = torch.zeros((nimg, heads, pad, 64), dtype=dtype)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((nimg, heads, 64, pad), dtype=dtype)
+    q[:, :, :ntok], k[:, :, :ntok] = q2, k16
+    t = torch.arange(ntok)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    vt[:, :, :, perm] = v16.transpose(-1, -2)
+    out = torch.zeros((nimg * ntok, heads * 64), device=dev, dtype=dtype)
+    ops.flash_attn(q.to(dev), k.to(dev), vt.to(dev), out, nimg, heads, ntok, pad)
+    s2 = q2.double() @ k16.double().transpose(-1, -2)                    # log2 domain
+    assert float(s2[..., :64, :64].max()) < -128.0 and float(s2[..., 64:128, :64].min()) > 140.0 and float(s2[..., 64:128, 64:].max()) < 125.0
+    ref = (torch.softmax(s2 * 0.6931471805599453, -1) @ v16.double()).permute(0, 2, 1, 3).reshape(nimg * ntok, heads * 64)
+    o = out.float().cpu().double()
+    assert torch.isfinite(o).all()
+    emax = float((o - ref).abs().max())
+    assert emax < (6e-2 if dtype == torch.bfloat16 else 8e-3), emax
+    ops.attn_set_mode(0)
+
+
 @pytest.mark.parametrize("pair", [(1, 2), (4, 5)])
 def test_flash_attention_queries_per_wave_bit_identical(pair):
     """32 and 64 queries per wave of one kernel family (32x32x16: modes 1 / 2, 16x16x32: modes 4 / 5) perform the same
