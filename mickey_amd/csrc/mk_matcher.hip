@@ -409,118 +409,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-// pass 2: the same correlation, outputs from registers -- through LDS, written as WHOLE 128-BYTE LINES.
-// In the accumulator layout a lane owns ONE column of a tile: stored from there an instruction writes 4 bytes per lane (round 4's
-// first version: 1.9 TB/s).  Round 4's second version bounced each wave's 32 x 64 block through a private LDS slice and wrote 256
-// contiguous bytes per row -- but output rows are n1 * 4 bytes apart (7752 at n1 = 1938), so every 256-byte piece starts and ends
-// somewhere inside a 128-byte line: of the 3 lines a piece touches only 1 is written whole (measured: 3.3 TB/s, L2-miss-side
-// traffic 1.42 x the bytes stored; a probe with every piece shifted onto a line boundary ran 21 % faster).
-// Now the WAVES waves of a workgroup compute WAVES adjacent 32 x 64 blocks of ONE row block and stage them in a shared LDS tile
-// of 32 rows x (WAVES * 64) columns in which row r is shifted right by (float index of its first element in HBM) mod 32.  LDS
-// column 4 q of a row is then the start of an aligned 16-byte chunk of the output and LDS columns 32 k .. 32 k + 31 are one whole
-// 128-byte line: the store phase walks the tile chunk by chunk (a wave instruction = 64 consecutive chunks = 8 whole lines of one
-// row), and only the two ends of a row's 1-KB (WAVES = 4) run are partial lines: 9 lines touched per 8 written instead of 3 per 2.
-// The three outputs go through two LDS tiles alternately (one barrier per output).
+// pass 2: the same correlation, outputs from registers -- through LDS.  In the accumulator layout a lane owns ONE column of
+// the tile: stored from there an instruction writes 4 bytes per lane, 128 contiguous bytes per output row (round 4's first
+// version: 1.9 TB/s, 0.75 ms for the three 480-MB outputs of 32 pairs -- the vector memory path, not HBM, was the limit).
+// Here a wave computes TWO column tiles (32 rows x 64 columns), transposes each output through an 8-KiB private LDS slice
+// (wave-local, LDS is in-order per wave: no barrier) and writes 16 bytes per lane, 256 contiguous bytes per row.
+// Round 5 built the writer round 4's notes asked for -- the 4 (8) waves of a workgroup on ONE row block, their 32 x 64 blocks
+// staged in a shared LDS tile whose rows are shifted by the row's offset inside its 128-byte line, stored as whole aligned
+// lines (9 lines touched per 8 written instead of 3 per 2), two tiles alternating, one barrier per output: commit 5 of round 5,
+// profiles/r05a_matcher_whole_line_writer.txt -- and it is SLOWER (stage 0.80 ms against 0.69 full, 0.54 against 0.44 lean):
+// half of this kernel's time is the latency of re-computing the correlation (three dependent L2 round trips per wave for 48
+// MFMAs), which eight independent waves per CU overlap with each other's stores and four barrier-coupled ones do not.
 // scores = 2^((v2 - lc2) + (v2 - lr2)), kp = scr0 (x) scr1, final = scores kp.
-template <int WAVES>
-struct ApplyGeom {
-  static constexpr int NC = WAVES * 64;    // output columns of a workgroup step
-  static constexpr int LD = NC + 32;       // LDS row length: the shift is < 32
-  static constexpr int CPR = LD / 4;       // 16-byte chunks per LDS row
-  static constexpr int TILE_FLOATS = RT * LD;
-  static constexpr int LDS_BYTES = 2 * TILE_FLOATS * 4;   // 72 KiB (4 waves: two workgroups per CU), 136 KiB (8 waves)
-};
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_split_apply_kernel(
+template <int VEC>   // floats per lane of an output store: 4 when the output rows are 16-byte aligned (n1 % 4 == 0), 2 for even n1
+                     // (n1 = 1938, the Map-free grid), else 1
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dual_softmax_split_apply_kernel(
     const uint4* __restrict__ P0, const uint4* __restrict__ P1, float scale2, const float* __restrict__ scr0,
     const float* __restrict__ scr1, const float* __restrict__ lse2, float* __restrict__ scores, float* __restrict__ kp,
-    float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int nunits, int nchunk) {
-  using G = ApplyGeom<WAVES>;
-  extern __shared__ __attribute__((aligned(16))) float apply_lds[];
-  int rb, by, b;
-  if (!decode_unit_grid<true>(nrb, nchunk, nunits, rb, by, b)) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* __restrict__ fin, int n0, int n1, int nmax, int nrb, int ntb, int gx, int nunits, int nchunk) {
+  __shared__ __attribute__((aligned(16))) float stage[4][RT * 64];
+  int bx, by, b;
+  if (!decode_unit_grid<true>(gx, nchunk, nunits, bx, by, b)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int i0 = rb * RT;
-  // workgroup steps of this column chunk: a step = WAVES pairs of column tiles
-  const int nsteps = ((ntb + 1) / 2 + WAVES - 1) / WAVES;
-  const int spc = (nsteps + nchunk - 1) / nchunk;
-  const int s0i = by * spc, s1i = min(nsteps, s0i + spc);
-  if (s0i >= s1i) return;   // workgroup-uniform
-  const long long rowg0 = (long long)b * n0 + i0;
+  const int rb = bx * 4 + wave, i0 = rb * RT;
+  if (rb >= nrb) return;
+  float* st = stage[wave];
+  SplitOperand a, bq;
+  a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
+  const int per = (ntb + nchunk - 1) / nchunk;
+  const int jt0 = by * per, jt1 = min(ntb, jt0 + per);
   float lr[16], s0[16];
-  int wofs[16];   // LDS float offset of (row, this wave's first column, this lane), the row's line shift included
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const int i = i0 + row;
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     const int ic = i < n0 ? i : n0 - 1;
     lr[r] = lse2[((long long)b * 2 + 0) * nmax + ic];
     s0[r] = scr0 ? scr0[(long long)b * n0 + ic] : 0.f;
-    const int shift = (int)(((rowg0 + row) * n1) & 31);   // (a step's first column is a multiple of 64: it does not move the shift)
-    wofs[r] = row * G::LD + shift + wave * 64 + l31;
   }
   const uint4* pb = P1 + (long long)b * ntb * SP_BLK_U4;
-  int use = 0;   // LDS tile the next output goes through
-  for (int st = s0i; st < s1i; ++st) {
-    const int jW = st * G::NC;                  // first column of the workgroup's window
-    const int jt = (st * WAVES + wave) * 2;     // this wave's pair of column tiles
-    const bool active = jt < ntb;               // wave-uniform
+  typedef float VT __attribute__((ext_vector_type(VEC)));
+  constexpr int LPR = 64 / VEC, RPI = 64 / LPR;   // lanes per 64-column row, rows per store instruction
+  const int dr = lane / LPR, dc = (lane % LPR) * VEC;
+  for (int jt = jt0; jt < jt1; jt += 2) {
     f32x16 acc[2];
-    float lc[2], s1[2];
-    if (active) {
-      SplitOperand a, bq;
-      a.load(P0 + ((long long)b * nrb + rb) * SP_BLK_U4, lane);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bq.load(pb + (long long)min(jt + t, ntb - 1) * SP_BLK_U4, lane);
-        acc[t] = corr_split(a, bq);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = (jt + t) * RT + l31;
-        const int jc = j < n1 ? j : n1 - 1;
-        lc[t] = lse2[((long long)b * 2 + 1) * nmax + jc];
-        s1[t] = scr1 ? scr1[(long long)b * n1 + jc] : 0.f;
-      }
+    for (int t = 0; t < 2; ++t) {
+      bq.load(pb + (long long)min(jt + t, ntb - 1) * SP_BLK_U4, lane);
+      acc[t] = corr_split(a, bq);
     }
-    const int ncols = min(G::NC, n1 - jW);      // valid columns of the window (> 0)
+    float lc[2], s1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = (jt + t) * RT + l31;
+      const int jc = j < n1 ? j : n1 - 1;
+      lc[t] = lse2[((long long)b * 2 + 1) * nmax + jc];
+      s1[t] = scr1 ? scr1[(long long)b * n1 + jc] : 0.f;
+    }
+    const int jbase = jt * RT;   // first column of the pair of tiles; columns of tile jt + 1 past jt1 / n1 are never stored
+    const int jlim = min(n1, min(jt + 2, jt1) * RT);
 #pragma unroll 1
-    for (int which = 0; which < 3; ++which) {   // 0 scores, 1 kp_scores, 2 final_scores
+    for (int which = 0; which < 3; ++which) {   // 0 scores, 1 kp_scores, 2 final_scores: one LDS round trip each
       float* out = which == 0 ? scores : which == 1 ? kp : fin;
-      if (!out) continue;   // workgroup-uniform
-      float* buf = apply_lds + use * G::TILE_FLOATS;
-      use ^= 1;
-      if (active) {
+      if (!out) continue;   // wave-uniform
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[t][r] * scale2;
-            const float pv = __builtin_amdgcn_exp2f((v - lc[t]) + (v - lr[r]));
-            const float kv = s0[r] * s1[t];
-            buf[wofs[r] + t * 32] = which == 0 ? pv : which == 1 ? kv : pv * kv;
-          }
-      }
-      // one barrier per output: the tile written two outputs ago was drained by every wave BEFORE it wrote the tile in between
-      __syncthreads();
-#pragma unroll 3
-      for (int id = tid; id < RT * G::CPR; id += WAVES * 64) {
-        const int r = id / G::CPR, q = id - r * G::CPR;
-        if (i0 + r >= n0) break;   // rows grow with id
-        const long long base = (rowg0 + r) * n1 + jW;   // float index of column jW of this row
-        const int c0 = 4 * q - (int)(base & 31);        // window-relative first column of this 16-byte-aligned chunk
-        if (c0 + 4 <= 0 || c0 >= ncols) continue;
-        const f32x4 v = *(const f32x4*)(buf + r * G::LD + 4 * q);
-        float* dst = out + (base + c0);
-        if (c0 >= 0 && c0 + 4 <= ncols) {
-          *(f32x4*)dst = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e >= 0 && c0 + e < ncols) dst[e] = v[e];
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * scale2;
+          const float pv = __builtin_amdgcn_exp2f((v - lc[t]) + (v - lr[r]));
+          const float kv = s0[r] * s1[t];
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          st[row * 64 + t * 32 + l31] = which == 0 ? pv : which == 1 ? kv : pv * kv;
         }
+#pragma unroll 8   // (VEC = 1 has 32 iterations: all of them in flight at once spill)
+      for (int it = 0; it < RT / RPI; ++it) {
+        const int row = dr + RPI * it, i = i0 + row, j = jbase + dc;
+        const VT val = *(const VT*)(st + row * 64 + dc);
+        if (i < n0 && j + VEC <= jlim) *(VT*)(out + ((long long)b * n0 + i) * n1 + j) = val;   // (jlim is a multiple of VEC)
       }
     }
   }
@@ -786,17 +752,7 @@ __global__ __launch_bounds__(1024) void mutual_collect_kernel(const int* __restr
 
 }  // namespace
 
-static int g_ds_chunk2 = 0;   // dual softmax (split path): column chunks of pass 2 per row block (0 = one workgroup step per workgroup)
-static int g_ds_waves = 4;    // ... and waves per workgroup of pass 2 (4: 1-KB row runs, two workgroups per CU; 8: 2-KB runs, one)
-
-template <int WAVES>
-static bool set_apply_lds() {
-  static bool done = false;
-  if (!done)
-    done = hipFuncSetAttribute((const void*)dual_softmax_split_apply_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ApplyGeom<WAVES>::LDS_BYTES) == hipSuccess;
-  return done;
-}
+static int g_ds_chunk2 = 0;   // dual softmax (split path): column chunks of pass 2 per row block (0 = one pair of tiles per wave)
 static int g_sk_group = 0;   // Sinkhorn: pairs iterated together (0: the whole batch per pass with non-temporal reads)
 
 extern "C" {
@@ -887,21 +843,20 @@ int mk_dual_softmax_split(const float* dsc0, const float* dsc1, const float* scr
                      dustbin * LOG2E, n0, n1, nmax, nrb, NCHUNK_S);
   MK_CHECK_LAUNCH();
   if (scores || kp_scores || final_scores) {
-    // pass 2 is a WRITER (see the kernel): g_ds_chunk2 column chunks per row block (dev knob; 0 = one workgroup step -- 256 or 512
-    // columns -- per workgroup: the fewest output rows in flight at a time); g_ds_waves = waves per workgroup (4 / 8)
-    const int waves = g_ds_waves == 8 ? 8 : 4;
-    const int nsteps = ((ntb + 1) / 2 + waves - 1) / waves;
-    const int nchunk2 = g_ds_chunk2 > 0 ? (g_ds_chunk2 < nsteps ? g_ds_chunk2 : nsteps) : nsteps;
-    const dim3 g2((unsigned)nrb * nchunk2 * ((B + 7) / 8 * 8));
-    if (waves == 8) {
-      MK_CHECK_ARG(set_apply_lds<8>(), "mk_dual_softmax_split: cannot reserve %d B of LDS", ApplyGeom<8>::LDS_BYTES);
-      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<8>, g2, dim3(512), ApplyGeom<8>::LDS_BYTES, st, P0, P1, scale2, scr0, scr1,
-                         lse2, scores, kp_scores, final_scores, n0, n1, nmax, nrb, ntb, B, nchunk2);
-    } else {
-      MK_CHECK_ARG(set_apply_lds<4>(), "mk_dual_softmax_split: cannot reserve %d B of LDS", ApplyGeom<4>::LDS_BYTES);
-      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<4>, g2, dim3(256), ApplyGeom<4>::LDS_BYTES, st, P0, P1, scale2, scr0, scr1,
-                         lse2, scores, kp_scores, final_scores, n0, n1, nmax, nrb, ntb, B, nchunk2);
-    }
+    // pass 2 is a WRITER: the fewer output rows the chip has in flight at a time, the more of its 256-byte row pieces meet open
+    // DRAM pages.  g_ds_chunk2 column chunks per row block (dev knob; 0 = one pair of column tiles per wave: the smallest window)
+    const int nchunk2 = g_ds_chunk2 > 0 ? g_ds_chunk2 : (ntb + 1) / 2;
+    const dim3 g2((unsigned)gx * nchunk2 * ((B + 7) / 8 * 8));
+    const bool a16 = ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 15) == 0);
+    if ((n1 & 3) == 0 && a16)
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<4>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
+    else if ((n1 & 1) == 0 && ((((uintptr_t)scores | (uintptr_t)kp_scores | (uintptr_t)final_scores) & 7) == 0))
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<2>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
+    else
+      hipLaunchKernelGGL(dual_softmax_split_apply_kernel<1>, g2, dim3(256), 0, st, P0, P1, scale2, scr0, scr1, lse2, scores, kp_scores,
+                         final_scores, n0, n1, nmax, nrb, ntb, gx, B, nchunk2);
     MK_CHECK_LAUNCH();
   }
   return MK_OK;
@@ -978,9 +933,7 @@ int mk_sinkhorn(const float* dsc0, const float* dsc1, const float* scr0, const f
 }
 
 int mk_dual_softmax_set_chunks(int chunks) {
-  MK_CHECK_ARG(chunks >= 0, "mk_dual_softmax_set_chunks: chunks + 1000 * (8 waves per workgroup ? 1 : 0)");
-  g_ds_chunk2 = chunks % 1000;
-  g_ds_waves = chunks / 1000 == 1 ? 8 : 4;
+  g_ds_chunk2 = chunks;
   return MK_OK;
 }
 
