@@ -202,6 +202,10 @@ int mk_gemm_set_tile(int mode) {
     g_half_rows = mode - 500;
     return MK_OK;
   }
+  if (mode == 600 || mode == 601) {   // dev: persistent tile loop of the 256x256 kernel on (where it applies) / off
+    g_pp64_persist = mode - 600;
+    return MK_OK;
+  }
   MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7,
                "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong)", mode);
   g_schedule = mode;

@@ -128,31 +128,79 @@ __device__ __forceinline__ float row16_sum(float v) {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 struct LnRowLoads16 {
   u32x4 v[4];
+  // J0 .. J1: which of the wave's four 1-KiB pieces (8 rows each) -- the persistent kernel fetches them in two rounds of two (8
+  // registers in flight through a K stage instead of 16)
+  template <int J0 = 0, int J1 = 4>
   __device__ __forceinline__ void issue(const GemmParams& p, int m0, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     const long long last = (long long)p.M * 128 - 16;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = J0; j < J1; ++j) {
       long long off = ((long long)(m0 + wave * 32 + j * 8) * 128) + lane * 16;
       off = off < last ? off : last;   // rows past M: any valid address (their parameters are never used)
       const char* a = (const char*)p.ln_stats + off;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(a) : "memory");
     }
   }
-  // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight
+  // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight; YOUNGER < 0: the caller has
+  // already waited (a counted vmcnt of its own behind which these loads are complete)
   // publish: this tile belongs to the first tile column and writes the row means for the next producer (rows m0 ...)
-  template <int YOUNGER>
+  template <int YOUNGER, int J0 = 0, int J1 = 4>
   __device__ __forceinline__ void finish(const GemmParams& p, int tid, float2* prm, int m0 = 0, bool publish = false) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
+    if constexpr (YOUNGER >= 0)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
+    else
+      asm volatile("" : "+v"(v[J0]), "+v"(v[J1 - 1]) : : "memory");
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = J0; j < J1; ++j) {
       const f32x4 f = __builtin_bit_cast(f32x4, v[j]);
       float s = f[0] + f[2], q = f[1] + f[3];
 #define MK_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
       MK_DPP_ADD(s, 0xB1);  MK_DPP_ADD(q, 0xB1);     // quad_perm [1,0,3,2]
       MK_DPP_ADD(s, 0x4E);  MK_DPP_ADD(q, 0x4E);     // quad_perm [2,3,0,1]
       MK_DPP_ADD(s, 0x141); MK_DPP_ADD(q, 0x141);    // row_half_mirror: the other quad of the 8-lane group
+#undef MK_DPP_ADD
+      const double mean = (double)s * (1.0 / 1024.0);
+      double var = (double)q * (1.0 / 1024.0) - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const float rstd = 1.0f / sqrtf((float)var + p.ln_eps);
+      if ((lane & 7) == 0) {
+        const int r = wave * 32 + j * 8 + (lane >> 3);
+        prm[r] = make_float2(rstd, -(float)mean * rstd);
+        if (publish && m0 + r < p.M) p.ln_shift_out[m0 + r] = (float)mean;
+      }
+    }
+  }
+};
+
+// The same statistics through LDS (persistent kernel, tiles after a workgroup's first): the wave's four 1-KiB pieces are copied
+// HBM/L2 -> LDS by the DMA engine, two at a time into a 2-KiB staging area of its own (16 KiB for the workgroup), while the
+// K loop of the tile runs -- no register is held across a stage (as registers, even 8 per lane pushed the consumer kernel
+// over the 256-register limit).  Same reduction, same order, same bits as LnRowLoads16.
+struct LnRowDma16 {
+  template <int J0>
+  __device__ __forceinline__ static void issue(const GemmParams& p, int m0, int wave, int lane, char* stage_lds) {
+    const long long last = (long long)p.M * 128 - 16;
+#pragma unroll
+    for (int j = J0; j < J0 + 2; ++j) {
+      const long long base = (long long)(m0 + wave * 32 + j * 8) * 128;   // wave-uniform
+      long long off = base + lane * 16;
+      off = off < last ? off : last;   // rows past M: any valid address (their parameters are never used)
+      glds16_sv((const char*)p.ln_stats, (unsigned)off, stage_lds + (wave * 2 + (j - J0)) * 1024);
+    }
+  }
+  template <int J0>
+  __device__ __forceinline__ static void finish(const GemmParams& p, int wave, int lane, float2* prm, const char* stage_lds, int m0,
+                                                bool publish) {
+#pragma unroll
+    for (int j = J0; j < J0 + 2; ++j) {
+      const f32x4 f = *(const f32x4*)(stage_lds + (wave * 2 + (j - J0)) * 1024 + lane * 16);
+      float s = f[0] + f[2], q = f[1] + f[3];
+#define MK_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+      MK_DPP_ADD(s, 0xB1);  MK_DPP_ADD(q, 0xB1);
+      MK_DPP_ADD(s, 0x4E);  MK_DPP_ADD(q, 0x4E);
+      MK_DPP_ADD(s, 0x141); MK_DPP_ADD(q, 0x141);
 #undef MK_DPP_ADD
       const double mean = (double)s * (1.0 / 1024.0);
       double var = (double)q * (1.0 / 1024.0) - mean * mean;
@@ -180,9 +228,12 @@ struct ShiftLoad {
       asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(a) : "memory");
     }
   }
-  template <int YOUNGER>
+  template <int YOUNGER>   // YOUNGER < 0: already waited for by the caller
   __device__ __forceinline__ void finish(int tid, int BM, float* shl) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(YOUNGER) : "memory");
+    if constexpr (YOUNGER >= 0)
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(YOUNGER) : "memory");
+    else
+      asm volatile("" : "+v"(v) : : "memory");
     if (tid < BM) shl[tid] = v;
   }
 };
@@ -562,17 +613,21 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[WMF][
 // ---------------------------------------------------------------------------------------------------------
 // LDS-staged epilogue of the full-line ping-pong kernel.  In the accumulator layout a lane owns 4 features of one
 // row, so a direct store instruction touches 16 rows x 32 B -- measured ~65 cycles per instruction and 4.4-7.2 us
-// per 256x256 tile (13-21 % of a K = 1024 tile).  After the K loop the 128-KiB ring is idle: each wave bounces its
-// 128x64 block through a private 16-KiB slice (wave-local, LDS is in-order per wave: no barrier) and then moves whole
-// rows: 16-bit outputs 16 B per lane = 8 full 128-byte lines per instruction, fp32 outputs (two 64-row halves) 4 x
-// 256 B.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
+// per 256x256 tile (13-21 % of a K = 1024 tile).  Each wave bounces its 128x64 block through a private LDS slice
+// (wave-local, LDS is in-order per wave: no barrier) and then moves whole rows: 16-bit outputs 16 B per lane = 8 full
+// 128-byte lines per instruction, fp32 outputs 4 x 256 B.
+// Round 5: the slice is 8 KiB (16-bit outputs: two rounds of 64 rows; fp32: four of 32), not 16, and it is two 4-KiB CHUNKS
+// -- wl0 = stage 1's A region + 4 KiB x wave, wl1 = stage 1's W region + 4 KiB x wave: exactly where THIS wave's own LDS-DMA
+// pieces of a stage land (piece = (4 x wave + j) KiB of the A half / of W).  The eight slices fill stage 1 of the ring and
+// nothing else: a persistent tile loop has the NEXT tile's stage 0 in flight into the other half of the ring while the
+// epilogue drains, and a wave that is done may issue its next A pieces without waiting for its neighbours.  The residual-stream read-modify-write and the q / k head-major stores become fully coalesced the same way;
 // only the V^T part of the qkv split keeps element stores (its rows are tokens at an arbitrary 16-group alignment).
 // XOR swizzles: 16-bit rows of 128 B, chunk ^ (row & 7); fp32 rows of 256 B, chunk ^ (row & 15).
 // SPLIT (split residual stream, §2.1b of LABNOTES.md) is instantiated for INTERIOR tiles only (no row / column predicates:
 // straight-line code; with per-row branches this variant pushed the whole kernel over 256 VGPRs and hipcc spilled half the
 // accumulators of every tile of every launch) -- edge tiles take the direct epilogue; FIN: fp32 rows out (last block).
 template <typename T, int EPI, int ACT, bool HAS_BIAS, bool LN = false, bool SPLIT = false, bool FIN = false, bool CONV = false>
-__device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm,
+__device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&acc)[8][4], char* wl0, char* wl1, int m0, int n0, int wm,
                                                   int wn, int lane, int g, const float2* lnp = nullptr) {
   using V4 = typename Lp<T>::V4;
   using V8 = typename Lp<T>::V8;
@@ -636,41 +691,6 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         return;
       }
     }
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      const int r = mi * 16 + fr;
-      // identity residual of a conv: a bordered feature map (one launch per forward takes this path)
-      const long long rrow = (CONV && p.resid_lp) ? bordered_row(min(mw + r, p.M - 1), p.H, p.Wd) : 0;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        f32x4 v = acc[mi][ni];
-        if (LN) v = v * prm[mi].x + (cs[ni] * prm[mi].y + bv[ni]);
-        else if (HAS_BIAS) v += bv[ni];
-        if (EPI == MK_EPI_QKV) {
-          if (which == 0) { const float qs = p.qscale; _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= qs; }
-        } else {
-          if (CONV && p.resid_lp) {
-            const int m = mw + r, n = nw + fg * 4 + ni * 16;
-            if (m < p.M && n < p.N) {
-              const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideResid_g + rrow * p.ldc + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
-            }
-          }
-          if (ACT == MK_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (ACT == MK_ACT_GELU) {
-            v = gelu_erf4(v);
-          }
-        }
-        V4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
-        const int c = ni * 2 + (fg >> 1);
-        *(V4*)(wl + r * 128 + ((c ^ (r & 7)) << 4) + (fg & 1) * 8) = o;
-      }
-    }
     const int rr = lane >> 3, c = lane & 7;
     const int n = nw + c * 8;
     // conv output that feeds the next conv: bordered rows (walked: the lane's rows are 8 apart)
@@ -678,28 +698,69 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
     BorderedRow bw;
     if (bord) bw.init(mw + rr, p.H, p.Wd);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int r = it * 8 + rr;
-      const int m = mw + r;
-      const V8 val = *(const V8*)(wl + r * 128 + ((c ^ (r & 7)) << 4));
-      const int extra = bord ? bw.extra : 0;
-      if (bord) bw.step(8, p.H, p.Wd);
-      if (m >= p.M || n >= p.N) continue;
-      T* dst;
-      if (EPI == MK_EPI_QKV) {
-        int img, tok;
-        img_tok(r, img, tok);
-        dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
-      } else {
-        dst = (T*)p.out_lp + (long long)g * p.strideOut_g + ((long long)m + extra) * p.ldc + n;
-      }
-      if (n + 8 <= p.N) {
-        *(V8*)dst = val;
-      } else {   // N % 8 == 4: the last chunk is half wide
-        V4 lo;
+    for (int h = 0; h < 2; ++h) {   // two rounds of 64 rows through the 8-KiB slice (rows 0..31 in chunk 0, 32..63 in chunk 1)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lo[e] = val[e];
-        *(V4*)dst = lo;
+      for (int mq = 0; mq < 4; ++mq) {
+        const int mi = h * 4 + mq;
+        const int r = mi * 16 + fr;
+        char* wrow = (mq < 2 ? wl0 : wl1) + ((mq & 1) * 16 + fr) * 128;
+        // identity residual of a conv: a bordered feature map (one launch per forward takes this path)
+        const long long rrow = (CONV && p.resid_lp) ? bordered_row(min(mw + r, p.M - 1), p.H, p.Wd) : 0;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          f32x4 v = acc[mi][ni];
+          if (LN) v = v * prm[mi].x + (cs[ni] * prm[mi].y + bv[ni]);
+          else if (HAS_BIAS) v += bv[ni];
+          if (EPI == MK_EPI_QKV) {
+            if (which == 0) { const float qs = p.qscale; _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] *= qs; }
+          } else {
+            if (CONV && p.resid_lp) {
+              const int m = mw + r, n2 = nw + fg * 4 + ni * 16;
+              if (m < p.M && n2 < p.N) {
+                const V4 rs = *(const V4*)((const T*)p.resid_lp + (long long)g * p.strideResid_g + rrow * p.ldc + n2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rs[e];
+              }
+            }
+            if (ACT == MK_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (ACT == MK_ACT_GELU) {
+              v = gelu_erf4(v);
+            }
+          }
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = to_lp<T>(v[e]);
+          const int cc = ni * 2 + (fg >> 1);
+          *(V4*)(wrow + ((cc ^ (fr & 7)) << 4) + (fg & 1) * 8) = o;
+        }
+      }
+#pragma unroll
+      for (int i8 = 0; i8 < 8; ++i8) {
+        const int it = h * 8 + i8;
+        const int r = it * 8 + rr;
+        const int m = mw + r;
+        const V8 val = *(const V8*)((i8 < 4 ? wl0 : wl1) + ((i8 & 3) * 8 + rr) * 128 + ((c ^ (rr & 7)) << 4));
+        const int extra = bord ? bw.extra : 0;
+        if (bord) bw.step(8, p.H, p.Wd);
+        if (m >= p.M || n >= p.N) continue;
+        T* dst;
+        if (EPI == MK_EPI_QKV) {
+          int img, tok;
+          img_tok(r, img, tok);
+          dst = (T*)(which == 0 ? p.q : p.k) + (((long long)img * p.heads + head) * p.ntok_pad + tok) * 64 + c * 8;
+        } else {
+          dst = (T*)p.out_lp + (long long)g * p.strideOut_g + ((long long)m + extra) * p.ldc + n;
+        }
+        if (n + 8 <= p.N) {
+          *(V8*)dst = val;
+        } else {   // N % 8 == 4: the last chunk is half wide
+          V4 lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = val[e];
+          *(V4*)dst = lo;
+        }
       }
     }
   } else {
@@ -765,10 +826,14 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         }
       }
     };
-    auto stage = [&](int half) {
+    // one QUARTER (32 rows: accumulator rows mi = 2 sub, 2 sub + 1 of the half) into the 8-KiB slice: rows 0..15 in chunk 0,
+    // 16..31 in chunk 1
+    auto stageq = [&](int half, int sub) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int mi = sub * 2 + m2;
         const int r = mi * 16 + fr;
+        char* wrow = (m2 == 0 ? wl0 : wl1) + fr * 256;
         const long long rrow = (CONV && p.resid_lp) ? bordered_row(min(mw + half * 64 + r, p.M - 1), p.H, p.Wd) : 0;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -796,7 +861,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
             }
           }
           const int cw = ni * 4 + fg;
-          *(f32x4*)(wl + r * 256 + ((cw ^ (r & 15)) << 4)) = v;
+          *(f32x4*)(wrow + ((cw ^ fr) << 4)) = v;
         }
       }
     };
@@ -834,7 +899,8 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
         const int m = mw + half * 64 + r;
         const int extraf = bordf ? bwf.extra : 0;
         if (bordf) bwf.step(4, p.H, p.Wd);
-        f32x4 val = *(const f32x4*)(wl + r * 256 + ((c ^ (r & 15)) << 4));
+        // slice row (it & 7) * 4 + rr of the quarter it >> 3 (written by stageq(half, it >> 3))
+        f32x4 val = *(const f32x4*)(((it & 4) ? wl1 : wl0) + ((it & 3) * 4 + rr) * 256 + ((c ^ ((it & 3) * 4 + rr)) << 4));
         if (SPLIT) val += bvd;
         const bool ok = SPLIT || (m < p.M && n < p.N);   // SPLIT: interior tiles only
         if (!ok) continue;
@@ -883,21 +949,27 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
       // next to the 64 accumulators still waiting) hipcc spilled.  Quarters, two of them in flight (64 registers):
       // every load still has at least one quarter of draining to land.
       preload(0, 0, 16);
-      stage(0);
+      stageq(0, 0);
       drain(0, 0, 8);
       preload(1, 0, 8);
+      stageq(0, 1);
       drain(0, 8, 16);
       preload(1, 8, 16);
-      stage(1);
+      stageq(1, 0);
       drain(1, 0, 8);
+      stageq(1, 1);
       drain(1, 8, 16);
     } else {
       preload(0);
-      stage(0);
+      stageq(0, 0);
+      drain(0, 0, 8);
+      stageq(0, 1);
       preload(1);
-      drain(0);
-      stage(1);
-      drain(1);
+      drain(0, 8, 16);
+      stageq(1, 0);
+      drain(1, 0, 8);
+      stageq(1, 1);
+      drain(1, 8, 16);
     }
   }
 }
@@ -909,18 +981,18 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
 // 2 = folded-LayerNorm producer (split residual stream), 3 = the same writing fp32 rows (last block): 2 and 3 together in
 // one kernel spill again.
 template <typename T, int KIND, bool CONV = false, int BN = 256>
-__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl, int m0, int n0, int wm, int wn,
-                                             int lane, int g, const float2* lnp = nullptr) {
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8][4], char* wl0, char* wl1, int m0, int n0, int wm,
+                                             int wn, int lane, int g, const float2* lnp = nullptr) {
   if constexpr (KIND == 2 || KIND == 3) {
     const bool interior = m0 + 256 <= p.M && n0 + BN <= p.N;   // workgroup-uniform
     if (KIND == 3) {   // LS_RESIDUAL with fp32 rows out (last block)
-      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g, lnp);
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     } else if (p.epi == MK_EPI_PATCH) {
-      if (interior) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
+      if (interior) epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
       else epilogue_impl<T, 8, MK_EPI_PATCH, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     } else {
-      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, false>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+      if (interior) epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true, false>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g, lnp);
       else epilogue_impl<T, 8, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true, false, true>(p, acc, m0, n0, wm, wn, lane, g);
     }
   } else if constexpr (KIND == 1) {
@@ -929,23 +1001,23 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[8
 #else
     constexpr bool LNE = true;
 #endif
-    if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
-    else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
-    else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, LNE>(p, acc, wl, m0, n0, wm, wn, lane, g, lnp);
+    if (p.epi == MK_EPI_QKV) epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true, LNE>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g, lnp);
+    else if (p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true, LNE>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g, lnp);
+    else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, LNE>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g, lnp);
   } else {
     switch (CONV ? MK_EPI_STORE : p.epi) {   // wave-uniform, once per output tile (a conv only ever stores)
-      case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
-      case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
-      case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl, m0, n0, wm, wn, lane, g); break;
+      case MK_EPI_LS_RESIDUAL: epilogue_lds_impl<T, MK_EPI_LS_RESIDUAL, MK_ACT_NONE, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g); break;
+      case MK_EPI_QKV: epilogue_lds_impl<T, MK_EPI_QKV, MK_ACT_NONE, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g); break;
+      case MK_EPI_PATCH: epilogue_lds_impl<T, MK_EPI_PATCH, MK_ACT_NONE, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g); break;
       default:
         if (!p.bias) {
-          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, false, false, false, false, CONV>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
+          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, false>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, false, false, false, false, CONV>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
         } else {
-          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl, m0, n0, wm, wn, lane, g);
-          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, false, false, false, CONV>(p, acc, wl, m0, n0, wm, wn, lane, g);
+          if (p.act == MK_ACT_RELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_RELU, true, false, false, false, CONV>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
+          else if (!CONV && p.act == MK_ACT_GELU) epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_GELU, true>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
+          else epilogue_lds_impl<T, MK_EPI_STORE, MK_ACT_NONE, true, false, false, false, CONV>(p, acc, wl0, wl1, m0, n0, wm, wn, lane, g);
         }
     }
   }
@@ -975,6 +1047,7 @@ __device__ __forceinline__ void pp_tile_coords(int id, int ntm, int ntn, int PP_
 }
 
 int num_cus();
+extern int g_pp64_persist;
 // schedule launchers (one translation unit each); amode = A_DENSE | A_CONV3, dtype = MK_BF16 | MK_F16
 int launch_pp64(const GemmParams& p, int groups, int dtype, int amode, hipStream_t st, int band_m);
 int launch_f32(const GemmParams& p, int groups, int amode, hipStream_t st);   // exact-fp32 parity mode (mk_gemm_f32.hip)

@@ -32,6 +32,7 @@ def _auto_tile():
         from mickey_amd import ops
         ops.gemm_set_tile(0)
         ops.gemm_set_tile(400)   # tile order back to automatic
+        ops.gemm_set_tile(600)   # persistent tile loop where it applies
         ops.attn_set_mode(0)
 
 
@@ -54,6 +55,75 @@ def test_gemm_tile_orders_are_bit_identical(M, N, K):
     assert rel(outs[400].float(), F.gelu(ref)) < 5e-3
     for order, o in outs.items():
         assert torch.equal(o, outs[400]), order
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("which", ["fc1", "qkv", "proj", "fc2", "last", "patch"])
+def test_persistent_gemm_is_bit_identical(which, dtype):
+    """The 256x256 kernel's PERSISTENT tile loop (round 5: one workgroup per CU walking a continuous K stream over its tiles, the
+    next tile's first operands prefetched under the current epilogue, row parameters / shifts of the folded LayerNorm staged
+    behind it; mk_gemm_set_tile 600 on / 601 off) against the one-tile-per-workgroup launch of the same kernel body: same tile
+    order, same summation order, same epilogues -- every output bit for bit, on problems of 372 - 608 tiles (> 256 workgroups:
+    each walks 1 - 3 tiles) with ragged last m-tiles, for the consumer (fc1 + GELU, qkv), producer (proj, fc2 with row centring;
+    the last block's fp32 rows) and patch-embed forms of the encoder."""
+    from mickey_amd import ops
+    dev = _dev()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *shape, s=1.0: torch.randn(shape, device=dev, generator=gen) * s  # noqa: E731
+    D, heads, ntok, pad = 1024, 16, 1939, 1984
+    ops.gemm_set_tile(7)
+
+    def run(persist):
+        ops.gemm_set_tile(600 if persist else 601)
+        torch.manual_seed(0)
+        if which in ("fc1", "qkv"):
+            nimg = 4
+            M, N = nimg * ntok, 4096 if which == "fc1" else 3072            # 31 m-tiles (last ragged) x 16 / 12
+            x = RUN["x"]
+            stats = RUN["stats"]
+            shift = torch.full((M,), float("nan"), device=dev)
+            if which == "fc1":
+                out = ops.gemm_ln(x, RUN["w"], RUN["b"], RUN["colsum"], stats, 1e-6, act=ops.ACT_GELU, shift_out=shift)
+                return [out, shift]
+            q = torch.zeros((nimg, heads, pad, 64), device=dev, dtype=dtype)
+            k = torch.zeros_like(q)
+            vt = torch.zeros((nimg, heads, 64, pad), device=dev, dtype=dtype)
+            ops.gemm_qkv_ln(x, RUN["w"], RUN["b"], RUN["colsum"], stats, 1e-6, q, k, vt, nimg, ntok, pad, heads, shift_out=shift)
+            return [q, k, vt, shift]
+        if which in ("proj", "fc2", "last"):
+            M = 20 * ntok                                                   # 152 m-tiles (last ragged) x 4
+            hi, lo = RUN["hi"].clone(), RUN["lo"].clone()
+            st = torch.full((M, D // 64, 2), float("nan"), device=dev)
+            x_out = torch.zeros((M, D), device=dev) if which == "last" else None
+            ops.gemm_ls_residual_ln(RUN["a"], RUN["w"], RUN["b"], RUN["gamma"], hi, lo, st, x_out=x_out, shift=RUN["shift"])
+            return [x_out] if which == "last" else [hi, lo, st]
+        nimg, npatch = 20, 1938                                             # patch embed: K = 640 (10 stages), 152 x 4 tiles
+        xh = torch.zeros((nimg * (npatch + 1), D), device=dev, dtype=dtype)
+        xl = torch.zeros_like(xh)
+        st = torch.zeros((nimg * (npatch + 1), D // 64, 2), device=dev)
+        ops.gemm_patch_embed_ln(RUN["a"], RUN["w"], RUN["b"], RUN["pos"], xh, xl, st, nimg, npatch)
+        return [xh, xl, st]
+
+    RUN = {}
+    if which in ("fc1", "qkv"):
+        M, N = 4 * ntok, 4096 if which == "fc1" else 3072
+        xf = rn(M, D) * (0.5 + 2 * torch.rand((M, 1), device=dev, generator=gen)) + rn(M, 1)
+        RUN.update(x=xf.to(dtype), stats=_slot_stats(xf).float(), w=rn(N, D, s=1 / 32).to(dtype), b=rn(N, s=0.1), colsum=rn(N))
+    elif which in ("proj", "fc2", "last"):
+        M, K = 20 * ntok, 4096 if which == "fc2" else 1024
+        xf = rn(M, D) * 2 + 0.7
+        hi = xf.to(dtype)
+        RUN.update(a=rn(M, K, s=0.5).to(dtype), w=rn(D, K, s=1 / math.sqrt(K)).to(dtype), b=rn(D), gamma=torch.rand((D,), device=dev, generator=gen),
+                   hi=hi, lo=(xf - hi.float()).to(dtype), shift=rn(M, s=0.3))
+    else:
+        RUN.update(a=rn(20 * 1938, 640, s=0.5).to(dtype), w=rn(D, 640, s=0.04).to(dtype), b=rn(D, s=0.1), pos=rn(1939, D, s=0.1))
+    one = run(False)
+    per = run(True)
+    again = run(True)
+    for a_, b_, c_ in zip(one, per, again):
+        assert bool(torch.isfinite(a_.float()).all())
+        assert torch.equal(a_, b_) and torch.equal(b_, c_)
+    ops.gemm_set_tile(600)
 
 
 @pytest.mark.parametrize("tile", [1, 2, 7])
