@@ -117,8 +117,12 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     geo = "_%d_%d_%d" % (nimg, gh, gw)   # bordered buffers: the workspace key carries the geometry (see encoder_forward)
     split = bool(getattr(W, "heads_split", False))   # 3x3 convs on split fp16 operands inside the fp32 head pipeline
 
-    def wsc(w):   # power-of-two scale of a split weight tensor's planes (weights.prepare)
-        return W.wscale[w.data_ptr()]
+    def wsc(w):   # power-of-two scale of a split weight tensor's planes (set by weights.prepare on the tensor object)
+        sc = getattr(w, "mk_scale", None)
+        if sc is None:
+            raise RuntimeError("split-operand weight without its plane scale: the tensor is not the one weights.prepare made "
+                               "(copied / moved weights must be re-prepared)")
+        return sc
 
     def plane_pair(name, shape):
         """Zeroed (hi, lo) fp16 planes of a bordered activation that a split conv WRITES (the next split conv's operands)."""

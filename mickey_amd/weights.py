@@ -139,13 +139,13 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
     W.heads_split = bool(heads_split)
     assert not W.heads_split or W.lp_heads == torch.float32, "split-operand convs sit in the fp32 head pipeline"
 
-    W.wscale = {}   # split mode: data_ptr of a split weight tensor -> the power-of-two scale of its planes
 
     def convw(t):   # weights of a 3x3 conv (+ shortcut columns) / a head linear: operand type of the heads, or the split K layout
         if W.heads_split:
             sc = split_weight_scale(t)
             out = split_conv_weight(t, sc).to(device=dev).contiguous()
-            W.wscale[out.data_ptr()] = sc
+            out.mk_scale = sc   # the power-of-two scale of its planes travels WITH the tensor object (a copy / .to() of it has
+            #                     no such attribute: pipeline.wsc raises instead of reading a stale scale by address)
             return out
         return t.to(device=dev, dtype=W.lp_heads).contiguous()
 
