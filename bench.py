@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
-TRAFFIC_SOURCE = "profiles/r04_pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/r05_pmc_traffic.json"
 
 
 STAGE_ROLES = {"encoder_gemm": ("encoder_gemm",), "attention": ("attention",), "conv_gemm": ("conv_gemm",),

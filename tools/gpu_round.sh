@@ -3,7 +3,7 @@
 # trace of the same command, the PMC passes (tools/profile_round.sh), the clock / matrix-pipe probe of the matrix kernels next to
 # hipBLASLt (tools/pmc_clock.sh, ONLY_GEMM=1 for the short form), the GEMM shapes against hipBLASLt, the folded-LayerNorm forms,
 # the matcher paths.  Outputs under gpurun_out/${TAG}_*; copy to profiles/.
-export TAG=${TAG:-r04}
+export TAG=${TAG:-r05}
 mkdir -p gpurun_out
 if [ -z "$SKIP_TESTS" ]; then   # SKIP_TESTS=1: the suite and smoke() ran in a call of their own
   timeout 2400 python -m pytest tests -q -m gpu -rf 2>&1 | tail -15 > gpurun_out/${TAG}_pytest_gpu.txt

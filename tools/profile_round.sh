@@ -7,7 +7,7 @@
 #      (FETCH_SIZE / WRITE_SIZE, read by bench.py when its source hash matches) and gpurun_out/${TAG}_pmc_busy.json
 #      (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE)
 # Copy what should be judged from gpurun_out/ to profiles/.
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 STEPS_BENCH=${STEPS_BENCH:-20}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -104,8 +104,8 @@ PY
 # the bench line LAST, with the traffic file of this very build in place (bench.py reads profiles/${TAG}_pmc_traffic.json when the
 # source hash matches), so that the line carries roofline.traffic and the per-stage traffic
 cd $R
-cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/r05_pmc_traffic.json   # (the file name bench.py reads: TRAFFIC_SOURCE)
 if [ -z "$SKIP_BENCH" ]; then
-  timeout 900 python bench.py --steps $STEPS_BENCH --warmup 3 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
+  timeout 900 python bench.py --steps $STEPS_BENCH --warmup 5 --detail gpurun_out/${TAG}_bench_detail.json 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
 fi
 head -c 900 $R/gpurun_out/${TAG}_bench_b32.json; echo; head -6 $R/gpurun_out/${TAG}_bench_b32_kernel_stats.csv | cut -c1-200
