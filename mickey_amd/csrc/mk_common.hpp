@@ -37,6 +37,17 @@ void mk_set_error(const char* fmt, ...);
 
 namespace mk {
 
+// Split-operand planes (x * scale = hi + lo in fp16) saturate at fp16's largest finite value.  A watcher word registered through
+// mk_split_watch_saturation (mickey_hip_dev.h; null = nobody watches, the default: no per-element work) gets bit 0 set by any
+// kernel that had to clamp -- NaN inputs included (fminf / fmaxf drop them) -- so that a head activation beyond the planes' range
+// (|x| > 1023 at the activation scale 64) cannot pass silently.
+extern int* g_sat_flag;   // host side: the registered device word (mk_norm.hip)
+__device__ __forceinline__ float sat16(float sv, int* flag) {
+  const float c = fminf(fmaxf(sv, -65504.f), 65504.f);
+  if (flag && c != sv) atomicOr(flag, 1);
+  return c;
+}
+
 // ---- MFMA wrappers: 16-bit operand type selects the instruction ---------------------------------
 template <typename T> struct Lp;  // low-precision operand traits
 template <> struct Lp<__bf16> {

@@ -355,7 +355,7 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
 // fp32 -> two fp16 planes, x * scale = hi + lo (22 mantissa bits); |x * scale| is saturated at fp16's largest finite value
 namespace {
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long rows, int cols4, long long ld_src4,
-                                                           float scale, uint2* __restrict__ hi, uint2* __restrict__ lo, long long ld_dst4) {
+                                                           float scale, uint2* __restrict__ hi, uint2* __restrict__ lo, long long ld_dst4, int* sat_flag) {
   const long long t = blockIdx.x * 256LL + threadIdx.x;
   if (t >= rows * cols4) return;
   const long long r = t / cols4;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   f16x4 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float v = fminf(fmaxf(x[e], -65504.f), 65504.f);
+    const float v = sat16(x[e], sat_flag);
     h[e] = (_Float16)v;
     l[e] = (_Float16)(v - (float)h[e]);
   }
@@ -381,7 +381,7 @@ int mk_split_planes(const float* src, long long rows, int cols, long long ld_src
   MK_CHECK_ARG((((uintptr_t)src | (uintptr_t)hi * 2 | (uintptr_t)lo * 2) & 15) == 0, "mk_split_planes: src must be 16-byte, planes 8-byte aligned");
   const long long n4 = rows * (cols / 4);
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, cols / 4,
-                     ld_src / 4, scale, (uint2*)hi, (uint2*)lo, ld_dst / 4);
+                     ld_src / 4, scale, (uint2*)hi, (uint2*)lo, ld_dst / 4, mk::g_sat_flag);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -394,7 +394,7 @@ int mk_gemm_grouped_split(const void* A_hi, const void* A_lo, int lda, long long
   p.npass = 3; p.acc_scale = acc_scale;
   p.strideA_g = strideA; p.strideW_g = strideW; p.strideBias_g = strideBias; p.strideOut_g = strideOut;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = ldc;
-  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; } else { p.out_f32 = (float*)out; }
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = g_sat_flag; } else { p.out_f32 = (float*)out; }
   if (int e = check_common(p, MK_F16)) return e;
   MK_CHECK_ARG(A_lo && out && groups > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldc % 4 == 0 && ldc >= N,
                "mk_gemm_grouped_split: bad args (K must be a multiple of %d)", BK);
@@ -413,7 +413,7 @@ int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in
   p.strideBias_g = strideBias; p.strideOut_g = strideOut;
   p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2_hi ? C2 : 0;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout;
-  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; } else { p.out_f32 = (float*)out; }
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = g_sat_flag; } else { p.out_f32 = (float*)out; }
   p.bord_out = out_bordered ? 1 : 0;
   if (int e = check_common(p, MK_F16)) return e;
   MK_CHECK_ARG(in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");

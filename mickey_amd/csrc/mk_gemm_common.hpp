@@ -35,6 +35,7 @@ struct GemmParams {
   // (fp16, v * plane_scale = hi + lo) instead of fp32 rows + a separate mk_split_planes pass
   void* out_lo;
   float plane_scale;
+  int* sat_flag;       // watcher word of the planes' saturation (mk_common.hpp: sat16), or null
   // epilogue
   int epi;
   int act;
@@ -532,7 +533,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmParams& p, f32x4 (&acc)[
           f16x4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float sv = fminf(fmaxf(v[e] * ps, -65504.f), 65504.f);   // saturate at fp16's largest finite value
+            const float sv = sat16(v[e] * ps, p.sat_flag);   // saturate at fp16's largest finite value
             oh[e] = (_Float16)sv;
             ol[e] = (_Float16)(sv - (float)oh[e]);
           }
@@ -932,7 +933,7 @@ __device__ __forceinline__ void epilogue_lds_impl(const GemmParams& p, f32x4 (&a
           f16x4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float sv = fminf(fmaxf(val[e] * ps, -65504.f), 65504.f);
+            const float sv = sat16(val[e] * ps, p.sat_flag);
             oh[e] = (_Float16)sv;
             ol[e] = (_Float16)(sv - (float)oh[e]);
           }

@@ -7,16 +7,20 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+namespace mk {
+int* g_sat_flag = nullptr;   // mk_split_watch_saturation
+}
+
 namespace {
 using namespace mk;
 
 // out_is_f32 == 2: the row goes out as the (hi, lo) fp16 operand planes of the split-operand head kernels
 // (mk_conv3x3_split / mk_gemm_grouped_split): y * scale = hi + lo, saturating at fp16's largest finite value
-__device__ __forceinline__ void store_planes(void* hi, void* lo, long long o, const f32x4& y, float scale) {
+__device__ __forceinline__ void store_planes(void* hi, void* lo, long long o, const f32x4& y, float scale, int* sat_flag) {
   f16x4 oh, ol;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float sv = fminf(fmaxf(y[e] * scale, -65504.f), 65504.f);
+    const float sv = sat16(y[e] * scale, sat_flag);
     oh[e] = (_Float16)sv;
     ol[e] = (_Float16)(sv - (float)oh[e]);
   }
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ b, float eps, void* out, int ldo,
                                                         int out_is_f32, float* resid, int ldr, int rows_out, int D,
                                                         int rows_per_img, int skip, int wgroup_rows, int bord_h, int bord_w,
-                                                        int bord_m, void* out_lo, float plane_scale) {
+                                                        int bord_m, void* out_lo, float plane_scale, int* sat_flag) {
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
   if (r0 >= rows_out) return;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
         if (out) {
           if (out_is_f32 == 2) {
-            store_planes(out, out_lo, ro * ldo + c, y, plane_scale);
+            store_planes(out, out_lo, ro * ldo + c, y, plane_scale, sat_flag);
           } else if (out_is_f32) {
             *(f32x4*)((float*)out + ro * ldo + c) = y;
           } else {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
                                                                const float* __restrict__ b, float eps, void* out, int ldo,
                                                                int out_is_f32, float* resid, int ldr, int rows_out, int D,
                                                                int rows_per_img, int skip, int wgroup_rows, int bord_h,
-                                                               int bord_w, int bord_m, void* out_lo, float plane_scale) {
+                                                               int bord_w, int bord_m, void* out_lo, float plane_scale, int* sat_flag) {
   const int lane = threadIdx.x & 63, half = lane >> 5, c = (lane & 31) * 4;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * LNN_TRIPS);
   if (r0 >= rows_out) return;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __re
         ro = gb * bordered_rows(bord_m / (bord_h * bord_w), bord_h, bord_w) + bordered_row(m, bord_h, bord_w);
       }
       if (out_is_f32 == 2) {
-        store_planes(out, out_lo, ro * ldo + c, y, plane_scale);
+        store_planes(out, out_lo, ro * ldo + c, y, plane_scale, sat_flag);
       } else if (out_is_f32) {
         *(f32x4*)((float*)out + ro * ldo + c) = y;
       } else {
@@ -319,6 +323,11 @@ void mk_set_error(const char* fmt, ...) {
 extern "C" {
 
 int mk_version(void) { return 100; }
+
+int mk_split_watch_saturation(int* device_flag) {
+  mk::g_sat_flag = device_flag;
+  return MK_OK;
+}
 const char* mk_last_error(void) { return g_err; }
 
 static int layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
@@ -335,7 +344,7 @@ static int layernorm_launch(const float* x, int ldx, const float* w, const float
     dim3 gridn((rows_out + 8 * LNN_TRIPS - 1) / (8 * LNN_TRIPS));
 #define MK_LNN(T_)                                                                                                         \
   hipLaunchKernelGGL((layernorm_narrow_kernel<T_>), gridn, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, mk::g_sat_flag)
     if (dtype == MK_BF16) MK_LNN(__bf16);
     else if (dtype == MK_F16) MK_LNN(_Float16);
     else MK_LNN(float);
@@ -346,7 +355,7 @@ static int layernorm_launch(const float* x, int ldx, const float* w, const float
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
 #define MK_LN(T_, V_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, mk::g_sat_flag)
   if (dtype == MK_BF16) {
     if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
   } else if (dtype == MK_F16) {

@@ -79,7 +79,9 @@ struct TopkWork {
   int* thr;                  // [R]
   unsigned* ncand;           // [R]
   unsigned* phist;           // [B][NBINS]   histogram of p itself (analytic threshold)
-  int* redo;                 // [1] set when a row collected fewer than k candidates above an analytic threshold
+  int* redo;                 // [B] per pair: set when one of its rows collected fewer than k candidates above an analytic threshold
+                             //     or a workgroup's queue overflowed -- the exact passes then redo THAT pair only (the others keep
+                             //     their skip-sampler draws: a pair's result never depends on its batch)
   unsigned long long* cand;  // [R][CAND_MAX]
   int* invalid;              // [1] or null
   int pair_base;             // global index of pair 0 of this call (keys the Philox streams)
@@ -110,14 +112,14 @@ __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsign
 // round trip whenever any of its 256 keys is a candidate -- inside the Philox loop that was ~25 % of the pass.
 constexpr int LCAP = 960;   // LDS candidate slots per row and block (expected ~25 at k = 2048, 128 blocks); overflow goes direct
 
-template <int PASS, bool REDO = false>  // 0: histogram, 1: collect; REDO: part of the exact fallback, runs only if w.redo is set
+template <int PASS, bool REDO = false>  // 0: histogram, 1: collect; REDO: part of the exact fallback, runs only for pairs whose w.redo is set
 __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restrict__ p, const float* __restrict__ noise,
                                                            unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
                                                            const unsigned long long* __restrict__ offp, TopkWork w,
                                                            int rows_per_pair, long long ncell) {
   __shared__ unsigned sh[RG * NBINS];   // pass 0: key histograms; pass 1: [RG][LCAP] candidates (2 words each) + counters
   __shared__ unsigned lcount[RG], lbase[RG];
-  if (REDO && *w.redo == 0) return;
+  if (REDO && w.redo[blockIdx.z] == 0) return;
   add_device_offset(off_lo, off_hi, offp);
   const int b = blockIdx.z, grp = blockIdx.y;
   const long long per = (ncell + gridDim.x - 1) / gridDim.x;
@@ -340,7 +342,8 @@ constexpr int SK_LCAP = 128;                 // LDS candidate slots per row and 
 constexpr int SK_HSLOTS = 4;                 // LDS slots of a thread for its hits (expected 0.9 per thread)
 constexpr float SK_DENSE = 0.1f;
 // A queue that overflows (a workgroup range with thousands of proposals: not a distribution a matcher produces) raises
-// `redo`: the exact histogram passes then redo the whole call from scratch.
+// `redo` of its pair: the exact histogram passes then redo THAT PAIR from scratch (the other pairs of the call keep what the
+// walk gave them).
 
 __global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restrict__ p, unsigned k0, unsigned k1, unsigned off_lo,
                                                            unsigned off_hi, const unsigned long long* __restrict__ offp,
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restri
     for (int h = 0; h < SK_HSLOTS; ++h)
       if (h < nown && base + h < (unsigned)SK_QCAP) hits[base + h] = slots[h * 256 + t];
   }
-  if (over) atomicOr(w.redo, 1);
+  if (over) atomicOr(&w.redo[b], 1);
   __syncthreads();
 
   // thinning + conditional race key of one proposed (cell, row); rnd = Philox keyed by (cell, row)
@@ -504,10 +507,10 @@ __global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restri
 }
 
 // one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
-__global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k) {
+__global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k, int rows_per_pair) {
   __shared__ unsigned part[256];
-  if (*w.redo == 0) return;   // exact fallback only
   const int row = blockIdx.x, t = threadIdx.x;
+  if (w.redo[row / rows_per_pair] == 0) return;   // exact fallback only, per pair
   const unsigned* h = w.hist + (long long)row * NBINS;
   // thread t owns bins [t*8, t*8+8); suffix sums from the top
   unsigned loc = 0;
@@ -625,14 +628,14 @@ __global__ __launch_bounds__(256) void exprace_athresh_kernel(TopkWork w, int ro
 
 // raise `redo` if a row fell short of k candidates although its threshold was not "everything", or overflowed its
 // candidate buffer (noise that is not Exp(1)-distributed can do either)
-__global__ void exprace_check_kernel(TopkWork w, int R, int k) {
+__global__ void exprace_check_kernel(TopkWork w, int R, int k, int rows_per_pair) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < R && ((w.thr[row] > 0 && w.ncand[row] < (unsigned)k) || w.ncand[row] > (unsigned)CAND_MAX)) atomicOr(w.redo, 1);
+  if (row < R && ((w.thr[row] > 0 && w.ncand[row] < (unsigned)k) || w.ncand[row] > (unsigned)CAND_MAX))
+    atomicOr(&w.redo[row / rows_per_pair], 1);
 }
-__global__ void exprace_rezero_kernel(TopkWork w, int R) {   // before the exact collect pass of the fallback
-  if (*w.redo == 0) return;
+__global__ void exprace_rezero_kernel(TopkWork w, int R, int rows_per_pair) {   // before the exact collect pass of the fallback
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < R) w.ncand[row] = 0;
+  if (row < R && w.redo[row / rows_per_pair] != 0) w.ncand[row] = 0;
 }
 
 // one block per row: sort the candidates (key desc, index asc), emit the top k
@@ -1328,7 +1331,7 @@ TopkWork carve(void* work, int R, int B, long long ncell) {
   w.thr = (int*)p;        p += (size_t)R * 4;
   w.ncand = (unsigned*)p; p += (size_t)R * 4;
   w.phist = (unsigned*)p; p += (size_t)B * NBINS * 4;
-  w.redo = (int*)p;       p += 4;
+  w.redo = (int*)p;       p += (size_t)B * 4;
   p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   w.cand = (unsigned long long*)p;  p += (size_t)R * CAND_MAX * 8;
   w.nblk = (ncell + SK_CELLS - 1) / SK_CELLS;
@@ -1343,7 +1346,7 @@ extern "C" {
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k, long long ncell) {
   (void)k;
   const long long R = (long long)B * rows_per_pair;
-  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4 + 16 + R * CAND_MAX * 8 + (long long)B * ((ncell + SK_CELLS - 1) / SK_CELLS) * 4;
+  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4LL * B + 16 + R * CAND_MAX * 8 + (long long)B * ((ncell + SK_CELLS - 1) / SK_CELLS) * 4;
 }
 int mk_exprace_set_mode(int mode) {
   MK_CHECK_ARG(mode == 0 || mode == 1, "mk_exprace_set_mode: 0 (skip sampler) or 1 (pre-filter pass)");
@@ -1371,7 +1374,7 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   TopkWork w = carve(work, R, B, ncell);
   w.invalid = invalid;
   w.pair_base = pair_base;
-  const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + 1;
+  const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + B;
   hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand | phist | redo are contiguous
   MK_CHECK_LAUNCH();
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), ol = (unsigned)offset, oh = (unsigned)(offset >> 32);
@@ -1404,10 +1407,10 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   }
   MK_CHECK_LAUNCH();
   // exact fallback (runs only if a row came up short: never observed, kept for adversarial inputs / injected noise)
-  hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k);
+  hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k, rows_per_pair);
   hipLaunchKernelGGL((exprace_scan_kernel<0, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
-  hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k);
-  hipLaunchKernelGGL(exprace_rezero_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R);
+  hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k, rows_per_pair);
+  hipLaunchKernelGGL(exprace_rezero_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, rows_per_pair);
   hipLaunchKernelGGL((exprace_scan_kernel<1, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(1024), (size_t)CAND_MAX * 8, st, p, w, idx, cnt, rows_per_pair, ncell,

@@ -121,6 +121,7 @@ class MickeyRelativePose(nn.Module):
         self.graph_max_images = int(amd.get("GRAPH_MAX_IMAGES", 8))
         self.graph_cache_size = int(amd.get("GRAPH_CACHE", 4))   # captured input signatures kept (LRU)
         self._graphs = collections.OrderedDict()
+        self._sat_flag = None   # split-operand heads: device word the plane-writing kernels report saturation into
         self._calls = 0
         self._ctr = None   # device-resident 2 * _calls: the Philox stream offset (read by the kernels, so a graph can advance it)
         # a single registered parameter carries the module's device (reference callers use
@@ -257,10 +258,21 @@ class MickeyRelativePose(nn.Module):
         im0, im1 = (t if t.stride(3) == 1 else t.contiguous() for t in (im0, im1))   # the patch kernel takes any outer strides
         imgs = [(im0, im1)] if same else [(im0,), (im1,)]
         outs = []
-        for im in imgs:
-            feat, gh, gw = pipeline.encoder_forward(W, self._ws, im)
-            scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, sum(t.shape[0] for t in im), gh, gw, self.cfg)
-            outs.append((scr, kps, depth, dsc, gh, gw))
+        if self.heads_split:
+            # split-operand heads hold activations as x * 64 = hi + lo in fp16: a value beyond +-1023 is clamped.  The kernels
+            # report it into this word (split_saturated() reads it): never silently
+            from . import ops
+            if self._sat_flag is None:
+                self._sat_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
+            ops.split_watch_saturation(self._sat_flag)
+        try:
+            for im in imgs:
+                feat, gh, gw = pipeline.encoder_forward(W, self._ws, im)
+                scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, sum(t.shape[0] for t in im), gh, gw, self.cfg)
+                outs.append((scr, kps, depth, dsc, gh, gw))
+        finally:
+            if self.heads_split:
+                ops.split_watch_saturation(None)
         if same:
             scr, kps, depth, dsc, gh, gw = outs[0]
             parts = [(scr[:B], kps[:B], depth[:B], dsc[:B], gh, gw), (scr[B:], kps[B:], depth[B:], dsc[B:], gh, gw)]
@@ -280,6 +292,16 @@ class MickeyRelativePose(nn.Module):
             data["kp_scores"] = kp
         data["final_scores"] = fin
         return data["kps0"], data["dsc0"], data["kps1"], data["dsc1"]
+
+    def split_saturated(self, reset=False):
+        """AMD.HEADS_DTYPE: split only: did any head activation since the last reset exceed the range of its fp16 operand planes
+        (|x| > 1023) and get clamped?  Synchronises the device.  Always False in the other modes."""
+        if self._sat_flag is None:
+            return False
+        v = bool(int(self._sat_flag.item()))
+        if reset:
+            self._sat_flag.zero_()
+        return v
 
     @torch.no_grad()
     def estimate_pose(self, data, return_inliers=False):

@@ -367,6 +367,15 @@ def counter_add(counter, inc):
     call("mk_counter_add", ptr(counter), int(inc), stream())
 
 
+def split_watch_saturation(flag):
+    """Dev / diagnostic (mickey_hip_dev.h): `flag` = a zero-initialised int32 [1] device tensor that every plane-writing kernel of
+    the split-operand head pipeline ORs 1 into when it had to clamp |x * scale| at fp16's largest finite value; None = stop
+    watching (the default).  Process-wide."""
+    if flag is not None:
+        assert flag.dtype == torch.int32 and flag.numel() >= 1 and flag.is_cuda
+    call("mk_split_watch_saturation", ptr(flag))
+
+
 def exprace_set_mode(mode):
     """Dev knob (mickey_hip_dev.h): 0 = skip sampler (default), 1 = the pre-filter collect pass."""
     call("mk_exprace_set_mode", int(mode))

@@ -619,6 +619,40 @@ def test_flash_attention_queries_per_wave_bit_identical(pair):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_split_planes_saturation_is_reported():
+    """x * 64 = hi + lo in fp16 saturates at |x| > 1023.  With a watcher word registered (mk_split_watch_saturation) every
+    plane-writing kernel reports a clamp; in range nothing is reported; without a watcher nothing is touched."""
+    from mickey_amd import ops
+    dev = _dev()
+    flag = torch.zeros((1,), device=dev, dtype=torch.int32)
+    x = torch.randn((64, 256), generator=g(3)).to(dev) * 100.0          # |x| < 1023
+    hi, lo = torch.empty_like(x, dtype=torch.float16), torch.empty_like(x, dtype=torch.float16)
+    w, b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    try:
+        ops.split_watch_saturation(flag)
+        ops.split_planes(x, hi, lo)
+        assert int(flag.item()) == 0
+        assert rel((hi.float() + lo.float()) / 64.0, x) < 1e-6
+        x2 = x.clone()
+        x2[5, 7] = 2000.0                                                # beyond the planes' range
+        ops.split_planes(x2, hi, lo)
+        assert int(flag.item()) == 1 and float(hi[5, 7]) == 65504.0
+        flag.zero_()
+        x3 = x.clone()
+        x3[9, 1] = float("nan")
+        ops.split_planes(x3, hi, lo)
+        assert int(flag.item()) == 1                                     # NaN is a clamp too (fminf / fmaxf drop it)
+        flag.zero_()
+        ops.layernorm(x * 0.01, w * 3000.0, b, 1e-6, out=(hi, lo))       # LayerNorm output (unit variance) x 3000: out of range
+        assert int(flag.item()) == 1
+        flag.zero_()
+        ops.split_watch_saturation(None)
+        ops.split_planes(x2, hi, lo)
+        assert int(flag.item()) == 0                                     # nobody watches: the word is left alone
+    finally:
+        ops.split_watch_saturation(None)
+
+
 def _to_bordered(x, nimg, H, W):
     """dense NHWC rows [..., nimg*H*W, C] -> bordered feature map [..., bordered_rows, C] (zeros elsewhere)"""
     from mickey_amd import ops

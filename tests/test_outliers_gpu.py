@@ -82,6 +82,7 @@ def _check(golden, cfg, dtype, size, **amd):
         assert torch.isfinite(data[k]).all(), k
         assert errs[k] <= tol[k], (k, errs[k], tol[k])
     assert torch.isfinite(R).all() and torch.isfinite(t).all()
+    _CACHE["last_model"] = model
     return data
 
 
@@ -90,6 +91,15 @@ def test_outlier_weights_182(golden, cfg, dtype):
     """2 pairs of 182x196, every output within 1.0 x the oracle-side floor of the operand type measured ON THESE WEIGHTS
     (fp32: 1e-4): LayerNorm fold + row centring + fold softmax all on (the defaults)."""
     _check(golden, cfg, dtype, "out182")
+
+
+def test_outlier_weights_reference_precision_split(golden, cfg):
+    """The reference's literal split -- fp16 encoder, fp32-grade heads on split fp16 planes (AMD.HEADS_DTYPE: split) -- on the
+    same weights: inside the reference's own fp16 floor, and no head activation left the range of its operand planes (|x| > 1023
+    would be clamped: the kernels report it, MickeyRelativePose.split_saturated)."""
+    _check(golden, cfg, "fp16", "out182", HEADS_DTYPE="split")
+    model = _CACHE.pop("last_model")
+    assert model.heads_split and model.split_saturated() is False
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

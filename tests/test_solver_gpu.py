@@ -240,6 +240,32 @@ def test_sampler_queue_overflow_takes_the_exact_fallback():
     assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
 
 
+def test_sampler_overflow_of_one_pair_leaves_the_others_alone():
+    """`redo` is per pair: a batch in which ONE pair overflows the skip sampler's queue (the spike matrix of the test above) sends
+    that pair through the exact fallback -- and the other pairs' draws are bit-identical to the same pairs in a batch where
+    nothing overflows (same seed / offset / pair positions): a pair's result does not depend on the batch it is in."""
+    from mickey_amd import ops
+    dev = _dev()
+    ncell, k, rows, B = 65536, 256, 20, 4
+    gen = torch.Generator().manual_seed(9)
+    benign = (torch.rand((B, ncell), generator=gen) + 0.5) * 1e-5
+    spike = torch.full((ncell,), 1e-7)
+    spikes = torch.arange(0, ncell, 16) + 5
+    spike[spikes] = 1.0
+    mixed = benign.clone()
+    mixed[2] = spike
+    idx_b, cnt_b = ops.exprace_topk(benign.to(dev).contiguous(), rows, k, seed=4, offset=7)
+    idx_m, cnt_m = ops.exprace_topk(mixed.to(dev).contiguous(), rows, k, seed=4, offset=7)
+    ib, im = idx_b.reshape(B, rows, k), idx_m.reshape(B, rows, k)
+    for pair in (0, 1, 3):
+        assert torch.equal(ib[pair], im[pair]), pair
+    assert int(cnt_m.min()) == k
+    on_spikes = torch.isin(im[2].reshape(-1).cpu().long(), spikes).float().mean()
+    assert float(on_spikes) > 0.99                      # the overflowing pair still gets a valid weighted draw
+    srt = im[2].long().sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+
+
 def test_sampler_degenerate_inputs(sampler_mode):
     from mickey_amd import ops
     dev = _dev()

@@ -1,4 +1,4 @@
-"""Markdown of DESIGN.md section 5 from a bench line (dev tool): python tools/design_table.py profiles/r04_bench_b32.json"""
+"""Markdown of DESIGN.md section 5 from a bench DETAIL object (dev tool): python tools/design_table.py profiles/r05_bench_detail.json"""
 import json
 import sys
 
@@ -20,11 +20,13 @@ for s in r["stages"]:
 print()
 print("| leg | pairs/s | ms/step | what |")
 print("|---|---|---|---|")
-for k, v in d["legs"].items():
-    print("| %s | %.1f | %.2f | %s |" % (k, v["value"], v["ms_per_step"], v["what"][:110]))
-sp, cb = d["single_pair"], d["cpu_baseline"]
-print("\nSingle pair (configs[1], hipGraph replay): %.2f ms.  CPU oracle: %.3f pairs/s on %d of %d cores (%s)." % (
-    sp["ms_per_pair"], cb["value"], cb["cores"], cb["cores_available"], cb["sample"][:80]))
-pm = d.get("precision_matched")
-if pm:
-    print("precision_matched:", json.dumps({k: v for k, v in pm.items() if k not in ("stages", "roofline")})[:1500])
+for k, v in (d.get("legs") or {}).items():
+    if "value" in v:
+        print("| %s | %.1f | %.2f | %s |" % (k, v["value"], v["ms_per_step"], v["what"][:110]))
+sp, cb = d.get("single_pair") or {}, d.get("cpu_baseline") or {}
+if sp and cb:
+    print("\nSingle pair (configs[1], hipGraph replay): %.2f ms.  CPU oracle: %.3f pairs/s on %d of %d cores (%s)." % (
+        sp["ms_per_pair"], cb["value"], cb["cores"], cb["cores_available"], cb["sample"][:80]))
+for k in ("sustained", "pcie_inclusive", "precision"):
+    if d.get(k):
+        print(k + ":", json.dumps(d[k])[:1200])
