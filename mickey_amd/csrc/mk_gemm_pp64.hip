@@ -281,6 +281,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   if constexpr (PRODUCER) shl.template finish<YOUNGER>(tid, 256, (float*)(smem + 2 * STAGE_BYTES));
   if constexpr (!PERSIST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   const int bstep = PERSIST ? (int)gridDim.x : 0;
+  // (measured and removed: every other workgroup of an XCD starting 10-60 k cycles late, so that the CUs' epilogue bursts do not
+  // coincide -- +-1 % on all four encoder shapes, profiles/r05f_gemm_persistent_stagger.txt)
   for (;;) {
     const int nbid = bid + bstep;
 #ifdef MK_P_NOTAIL
