@@ -561,9 +561,19 @@ def roofline_entry(stages, by, B, dtype, model):
     return roof
 
 
+_T0 = time.perf_counter()
+
+
+def tick(what):
+    """Wall-clock account of the run on stderr (what the driver's clock around the whole command is spent on)."""
+    sys.stderr.write("bench.py t+%6.1fs %s\n" % (time.perf_counter() - _T0, what))
+    sys.stderr.flush()
+
+
 def main(argv=None):
     args = parse_args(argv)
     import torch
+    tick("torch imported")
     mode, world = resolve_world(args, os.environ, args.gpus if args.stub else torch.cuda.device_count())
     if mode == "spawn":
         sys.exit(spawn_ranks(world, sys.argv[1:] if argv is None else list(argv)))
@@ -593,6 +603,8 @@ def main(argv=None):
         ops.gemm_set_tile(500)
     ops.attn_set_mode(args.attn_mode)
 
+    sd_cache = {}   # the synthetic checkpoint of an architecture is drawn once (350 M random numbers) and shared by the legs
+
     def make_model(dtype, heads=None, arch="vit_large", matcher=None):
         cfg = default_cfg()
         cfg["AMD"]["ENCODER_DTYPE"] = dtype
@@ -604,7 +616,10 @@ def main(argv=None):
         cfg["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = syn.VIT_ARCH[arch][0]
         if matcher:
             cfg["FEATURE_MATCHER"]["TYPE"] = matcher
-        sd = syn.mickey_state_dict(cfg, seed=0, arch=arch)
+        key = (arch, cfg["FEATURE_MATCHER"]["TYPE"])
+        if key not in sd_cache:
+            sd_cache[key] = syn.mickey_state_dict(cfg, seed=0, arch=arch)
+        sd = sd_cache[key]
         m = MickeyRelativePose(cfg)
         m.load_state_dict(sd)
         return m.to(dev), cfg, sd
@@ -620,7 +635,11 @@ def main(argv=None):
     data0 = {k: v.to(dev) for k, v in batch.items()}
     gatherer = D.PoseGatherer(dev) if use_dist else None
 
+    if rank == 0:
+        tick("model + batch ready")
     dt, last, poses = measure(model, data0, args, use_dist, world, gatherer, prof)
+    if rank == 0:
+        tick("headline measured")
     graphed = len(model._graphs) > 0
     ev_steps = args.steps
     if graphed and prof is not None:
@@ -684,6 +703,8 @@ def main(argv=None):
                                   "hip_graph": len(model._graphs) > 0, "what": "BASELINE.json configs[1]: batch of one pair, same model"}
         except Exception as e:   # extra information: must not cost the headline line
             out["single_pair"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if single:
+        tick("single pair measured")
     if single and args.include_h2d:
         from mickey_amd import input_pipeline as ip
         try:
@@ -752,9 +773,11 @@ def main(argv=None):
         "1.72 GB here), fp16 operands", "fp16", 3, 1, batch_pairs=8, hw=(720, 1280), dominant="matcher", matcher="Sinkhorn")
 
     if rank == 0:
+        tick("legs measured")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, sd)
+                tick("cpu baseline measured")
             except Exception as e:   # the line must still be printed (the contract's required keys stay present)
                 out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed",
                                        "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
