@@ -129,32 +129,25 @@ __device__ __forceinline__ float row16_sum(float v) {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 struct LnRowLoads16 {
   u32x4 v[4];
-  // J0 .. J1: which of the wave's four 1-KiB pieces (8 rows each) -- the persistent kernel fetches them in two rounds of two (8
-  // registers in flight through a K stage instead of 16)
-  template <int J0 = 0, int J1 = 4>
   __device__ __forceinline__ void issue(const GemmParams& p, int m0, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     const long long last = (long long)p.M * 128 - 16;
 #pragma unroll
-    for (int j = J0; j < J1; ++j) {
+    for (int j = 0; j < 4; ++j) {
       long long off = ((long long)(m0 + wave * 32 + j * 8) * 128) + lane * 16;
       off = off < last ? off : last;   // rows past M: any valid address (their parameters are never used)
       const char* a = (const char*)p.ln_stats + off;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(a) : "memory");
     }
   }
-  // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight; YOUNGER < 0: the caller has
-  // already waited (a counted vmcnt of its own behind which these loads are complete)
+  // YOUNGER = VMEM instructions this wave issued after issue() that may still be in flight
   // publish: this tile belongs to the first tile column and writes the row means for the next producer (rows m0 ...)
-  template <int YOUNGER, int J0 = 0, int J1 = 4>
+  template <int YOUNGER>
   __device__ __forceinline__ void finish(const GemmParams& p, int tid, float2* prm, int m0 = 0, bool publish = false) {
-    if constexpr (YOUNGER >= 0)
-      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
-    else
-      asm volatile("" : "+v"(v[J0]), "+v"(v[J1 - 1]) : : "memory");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int j = J0; j < J1; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const f32x4 f = __builtin_bit_cast(f32x4, v[j]);
       float s = f[0] + f[2], q = f[1] + f[3];
 #define MK_DPP_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))

@@ -285,11 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // coincide -- +-1 % on all four encoder shapes, profiles/r05f_gemm_persistent_stagger.txt)
   for (;;) {
     const int nbid = bid + bstep;
-#ifdef MK_P_NOTAIL
-    const bool has_next = false;
-#else
     const bool has_next = PERSIST && nbid < ntiles;   // workgroup-uniform
-#endif
     // the tile whose stage 0 is prefetched in the last two stages: the next one -- or, behind the last tile, the current one
     // again (64 KiB of valid operands nobody reads, once per workgroup: keeps ONE code path through the tail; with a branch
     // around it hipcc renamed all 128 accumulators at the join and spilled a tile's worth of them per stage)
@@ -332,11 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
                                 ln && p.ln_shift_out != nullptr && n0 == 0);
       }
     };
-#ifdef MK_P_NOLN
-    ln_pending = false;
-#else
     ln_pending = PERSIST && bid != (int)blockIdx.x;
-#endif
     int kt0 = 0;
     if (wm == 0) {
       if constexpr (PERSIST) {   // (nk >= 4: launch_k)
@@ -387,11 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     m0 = m1;
     n0 = n1;
     asm volatile("" : "+s"(m0), "+s"(n0));   // not the values the tail above derived aoff / woff from: those die with the tail
-#ifndef MK_P_NOLN
     refresh_lane();
     if (ln_fast) LnRowDma16::issue<0>(p, m0, wave, lane, smem + LN_STAGE_OFF);
     if constexpr (PRODUCER) shl.issue(p, m0, tid, 256);
-#endif
   }
 }
 

@@ -40,8 +40,7 @@ __device__ __forceinline__ f32x16 corr_tile(const float* sA, const float* sB, in
   const int l31 = lane & 31, hi = lane >> 5;
   const float* pa = sA + hi * MT + wi * 32 + l31;
   const float* pb = sB + hi * MT + wj * 32 + l31;
-#pragma unroll 8
-  for (int kk = 0; kk < C / 2; ++kk) {
+  for (int kk = 0; kk < C / 2; ++kk) {   // (C is a runtime value: the unroll is hipcc's call)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * 2 * MT], pb[kk * 2 * MT], acc, 0, 0, 0);
   }
   return acc;
@@ -54,7 +53,6 @@ __device__ __forceinline__ f32x16 corr_tile(const float* sA, const float* sB, in
 // barriers.  (The previous version staged 64 KiB through LDS with scalar loads per 64x64 tile and ran at ~10 % of the
 // fp32 matrix rate.)  Everything is kept in the log2 domain: v2 = S / T * log2(e), exp2 is one v_exp_f32.
 constexpr int RT = 32;       // rows per wave, columns per streamed tile
-constexpr int NCHUNK2 = 4;   // column chunks of pass 2
 
 __device__ __forceinline__ void lse2_merge(float& m, float& s, float m2, float s2) {
   const float M = fmaxf(m, m2);
