@@ -127,7 +127,7 @@ def build(force=False, save_temps=False, verbose=True):
     cc = hipcc()
     # -Rpass-analysis=kernel-resource-usage: per-kernel registers / scratch / spills, parsed into build/resource_usage.json
     # (tests/test_host_cpu.py asserts that no hot kernel spills: one register-hungry epilogue variant inlined into the GEMM
-    # kernel once made hipcc spill the accumulators of every tile of every launch, +25 % on all GEMMs, LABNOTES.md section 6)
+    # kernel once made hipcc spill the accumulators of every tile of every launch, +25 % on all GEMMs, profiles/README.md, round 2)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage",
              "-I", INCLUDE]
     jobs = []

@@ -148,7 +148,7 @@ def test_intrinsics_rescale_matches_the_reference_formula():
 def test_no_product_kernel_spills_registers():
     """Per-kernel register report of the build (hipcc -Rpass-analysis=kernel-resource-usage -> build/resource_usage.json).
     All epilogues of a GEMM kernel share ONE register allocation: a variant over 256 VGPRs makes hipcc spill the
-    accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward, LABNOTES.md section 6).
+    accumulators of every tile of every launch (it happened: +25 % on all GEMMs of the forward, profiles/README.md, round 2).
     No kernel of the library is exempt.  The report is written by build(); a checkout whose objects were built elsewhere
     (no json) skips."""
     import glob
