@@ -638,7 +638,89 @@ __global__ void exprace_rezero_kernel(TopkWork w, int R, int rows_per_pair) {   
   if (row < R && w.redo[row / rows_per_pair] != 0) w.ncand[row] = 0;
 }
 
-// one block per row: sort the candidates (key desc, index asc), emit the top k
+// one block per row: sort the candidates (key desc, index asc), emit the top k.
+// Bitonic network over np2 = 2^m >= nc slots (empty slots hold 0: they sink to the end), thread t owning the E = np2 / 1024
+// consecutive slots t E .. t E + E - 1 IN REGISTERS.  A compare-exchange distance j is
+//   j < E            inside the thread: register to register;
+//   E <= j < 64 E    inside the wave: the partner's value comes by a lane exchange (two 32-bit __shfl_xor), no barrier;
+//   j >= 64 E        across waves: through LDS (store, barrier, read the partner slot, barrier).
+// For ~2600 candidates (np2 = 4096, E = 4) that is 23 + 45 + 10 passes instead of 78 LDS passes with a workgroup barrier each
+// (round 4: 133 us per launch, and the same 133 us of latency for ONE pair's 20 rows); every slot's new value is computed by its
+// owner from (own, partner) -- max or min of the pair by its side of the exchange -- so no slot is written by two threads.
+// The order is a total order on distinct 64-bit words (key bits | inverted cell index): the result does not depend on the network.
+template <int E, int J>   // compare-exchange at distance J < E inside the thread (register indices are compile-time)
+__device__ __forceinline__ void select_thread_pass(unsigned long long (&v)[E], int kk, int t) {
+  if constexpr (J < E) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if ((e & J) == 0) {
+        const int i = t * E + e;
+        const bool desc = (i & kk) == 0;
+        const unsigned long long x = v[e], y = v[e | J];
+        const bool sw = desc ? (x < y) : (x > y);
+        v[e] = sw ? y : x;
+        v[e | J] = sw ? x : y;
+      }
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void select_sort(unsigned long long (&v)[E], unsigned long long* keys, int np2, int t) {
+  for (int kk = 2; kk <= np2; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j < E) {
+        if (j == 1) select_thread_pass<E, 1>(v, kk, t);
+        else if (j == 2) select_thread_pass<E, 2>(v, kk, t);
+        else select_thread_pass<E, 4>(v, kk, t);
+      } else if (j < 64 * E) {
+        const int lm = j / E;            // lane distance
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = t * E + e;
+          const unsigned long long x = v[e];
+          const unsigned lo = __shfl_xor((unsigned)x, lm, 64), hi = __shfl_xor((unsigned)(x >> 32), lm, 64);
+          const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+          const bool lower = (i & j) == 0, desc = (i & kk) == 0;
+          const bool want_max = lower == desc;
+          v[e] = want_max ? (x > y ? x : y) : (x < y ? x : y);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) keys[t * E + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = t * E + e;
+          const unsigned long long x = v[e], y = keys[i ^ j];
+          const bool lower = (i & j) == 0, desc = (i & kk) == 0;
+          const bool want_max = lower == desc;
+          v[e] = want_max ? (x > y ? x : y) : (x < y ? x : y);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void select_run(const unsigned long long* __restrict__ cand, unsigned long long* keys, int nc, int np2,
+                                           int* __restrict__ out, int take) {
+  const int t = threadIdx.x;
+  unsigned long long v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    v[e] = i < nc ? cand[i] : 0ull;
+  }
+  select_sort<E>(v, keys, np2, t);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = t * E + e;
+    if (i < take) out[i] = (int)(0xffffffffu - (unsigned)(v[e] & 0xffffffffu));
+  }
+}
+
 __global__ __launch_bounds__(1024) void exprace_select_kernel(const float* __restrict__ p, TopkWork w, int* __restrict__ idx,
                                                               int* __restrict__ cnt, int rows_per_pair, long long ncell,
                                                               int k) {
@@ -646,28 +728,15 @@ __global__ __launch_bounds__(1024) void exprace_select_kernel(const float* __res
   const int row = blockIdx.x;
   const unsigned nc_raw = w.ncand[row];
   const int nc = (int)min(nc_raw, (unsigned)CAND_MAX);
-  int np2 = 1;
+  int np2 = 1024;                    // at least one slot per thread (E = 1); CAND_MAX = 8192 -> E <= 8
   while (np2 < nc) np2 <<= 1;
-  if (np2 < 2) np2 = 2;
   const unsigned long long* cand = w.cand + (long long)row * CAND_MAX;
-  for (int i = threadIdx.x; i < np2; i += 1024) keys[i] = i < nc ? cand[i] : 0ull;
-  __syncthreads();
-  for (int kk = 2; kk <= np2; kk <<= 1) {
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < np2; i += 1024) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
-          const bool desc = (i & kk) == 0;
-          if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
   const int take = min(nc, k);
-  for (int i = threadIdx.x; i < take; i += 1024)
-    idx[(long long)row * k + i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffu));
+  int* out = idx + (long long)row * k;
+  if (np2 == 1024) select_run<1>(cand, keys, nc, np2, out, take);        // (workgroup-uniform)
+  else if (np2 == 2048) select_run<2>(cand, keys, nc, np2, out, take);
+  else if (np2 == 4096) select_run<4>(cand, keys, nc, np2, out, take);
+  else select_run<8>(cand, keys, nc, np2, out, take);
   if (threadIdx.x == 0) {
     cnt[row] = nc_raw > (unsigned)CAND_MAX ? -1 : take;
     if (nc_raw == 0 && w.invalid) atomicOr(w.invalid, 1);
