@@ -139,3 +139,15 @@ def test_default_arguments_keep_the_driver_run_short():
     assert lean.leg_set == set() and lean.no_cpu_baseline and lean.no_single
     with pytest.raises(SystemExit):
         bench.parse_args(["--legs", "nonsense"])
+
+
+def test_compact_line_at_eight_gpus_stays_small():
+    """The N = 8 line carries min / max of the ranks' own step times and drops the per-rank placements: still < 3 KB."""
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_b32.json")))
+    detail["n_gpus"] = 8
+    detail["per_rank_ms_per_step"] = {"min": 115.1, "max": 117.2, "all": [116.0] * 8}
+    detail["config"]["affinity"] = [{"numa_node": i // 4, "cpus": list(range(32 * i, 32 * i + 32)), "n_cpus": 32}] * 8
+    txt = bench.compact_line(detail, "gpurun_out/bench_detail.json")
+    assert len(txt) < bench.LINE_LIMIT
+    line = json.loads(txt)
+    assert line["n_gpus"] == 8 and line["per_rank_ms_per_step"] == {"min": 115.1, "max": 117.2} and "affinity" not in line["config"]
