@@ -146,7 +146,7 @@ def test_compact_line_at_eight_gpus_stays_small():
     detail = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_b32.json")))
     detail["n_gpus"] = 8
     detail["per_rank_ms_per_step"] = {"min": 115.1, "max": 117.2, "all": [116.0] * 8}
-    detail["config"]["affinity"] = [{"numa_node": i // 4, "cpus": list(range(32 * i, 32 * i + 32)), "n_cpus": 32}] * 8
+    detail["config"]["affinity"] = [{"numa_node": r // 4, "cpus": list(range(32 * r, 32 * r + 32)), "n_cpus": 32} for r in range(8)]
     txt = bench.compact_line(detail, "gpurun_out/bench_detail.json")
     assert len(txt) < bench.LINE_LIMIT
     line = json.loads(txt)
