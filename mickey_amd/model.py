@@ -222,6 +222,7 @@ class MickeyRelativePose(nn.Module):
         self._dev_weights = None
         self._graphs = collections.OrderedDict()
         self._ctr = None
+        self._sat_flag = None
         return super()._apply(fn, *a, **k)
 
     @property
