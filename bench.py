@@ -837,11 +837,20 @@ def compact_line(out, detail_path=None):
     if detail_path:
         line["detail"] = detail_path
     txt = json.dumps(line, separators=(",", ":"))
-    if len(txt) >= LINE_LIMIT:   # cannot happen with the keys above; keep the contract's keys whatever else was added
-        for k in ("stages", "ref_precision", "detail"):
-            line.pop(k, None)
+    # cannot happen with the keys above; if it ever does, optional keys go first and free-text fields are cut -- the line is
+    # printed whatever happens (an oversized or missing line is an unmeasured round)
+    for k in ("ref_precision", "detail", "stages", "single_pair_ms", "per_rank_ms_per_step"):
+        if len(txt) < LINE_LIMIT:
+            break
+        line.pop(k, None)
         txt = json.dumps(line, separators=(",", ":"))
-    assert len(txt) < LINE_LIMIT, len(txt)
+    if len(txt) >= LINE_LIMIT:
+        for obj, keys in ((line.get("roofline") or {}, ("traffic_source", "kernel")), (line.get("cpu_baseline") or {}, ("sample",)),
+                          (line.get("config") or {}, ("workload", "parallelism"))):
+            for k in keys:
+                if isinstance(obj.get(k), str):
+                    obj[k] = obj[k][:60]
+        txt = json.dumps(line, separators=(",", ":"))
     return txt
 
 
