@@ -150,14 +150,14 @@ class StageProfiler:
         timed("conv3x3", "conv_gemm",
               lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, act=0, in2=None, C2=0, **k:
               2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
-        # split-operand convs (AMD.HEADS_DTYPE: split): the SAME algorithmic flops -- the three MFMA sweeps per product are the
+        # split-operand convs (AMD.HEADS_DTYPE: split): the SAME algorithmic flops -- the three MFMA products per multiply are the
         # implementation's -- and the fp32 -> (hi, lo) plane conversions in front of them
         timed("conv3x3_split", "conv_gemm",
               lambda in1, C1, w, bias, out, Cout, groups, nimg, Hh, Ww, act=0, in2=None, C2=0, **k:
               2.0 * groups * nimg * Hh * Ww * Cout * (9 * C1 + (C2 if in2 is not None else 0)))
-        timed("split_planes", "split_planes", lambda x, hi, lo, scale=64.0: 8.0 * x.numel())
+        timed("split_planes", "split_planes", lambda x, hi, lo, scale=64.0, **k: 8.0 * x.numel())
         timed("gemm_grouped_split", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:
-              float(groups) * (M * K * 4 + N * 3 * K * 2 + M * N * 4))
+              float(groups) * (M * K * 4 + N * 2 * K * 2 + M * N * 4))
         # the head linears (K = 128..256, fp32 qkv outputs) are write-bound: 1 flop per 3 bytes; priced against HBM
         timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:
               float(groups) * (M * K * esz(a) + N * K * esz(w) + M * N * esz(out)))

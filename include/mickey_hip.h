@@ -13,7 +13,8 @@
  *   - functions only enqueue work on `stream`: no allocation, no synchronisation, no host<->device
  *     copies.  Scratch memory is passed in by the caller (sizes documented per function).
  *   - re-entrant: no mutable globals besides the thread-local error string (the process-wide schedule
- *     selectors for benchmarks / tests live in mickey_hip_dev.h, not in this ABI).
+ *     selectors for benchmarks / tests live in mickey_hip_dev.h, not in this ABI); state a kernel reports
+ *     (e.g. the saturation word of the split-operand planes) is a per-call argument.
  *   - "lp" (low precision) buffers hold bf16 or fp16 according to `dtype` (MK_BF16 / MK_F16);
  *     accumulation is always fp32.  dtype MK_F32 is the exact parity mode: "lp" buffers hold fp32 and
  *     every contraction runs on the fp32-input MFMA (the reference's FLOAT16: False path and its
@@ -148,10 +149,10 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
 
 /* The same LayerNorm writing its rows as the (hi, lo) fp16 operand planes of the split-operand head kernels (mk_conv3x3_split,
  * mk_gemm_grouped_split; AMD.HEADS_DTYPE: split): LN(x) * plane_scale = hi + lo, both [.., ldo] fp16, dense or bordered as above
- * (no fp32 copy, no separate mk_split_planes pass). */
+ * (no fp32 copy, no separate mk_split_planes pass).  sat_flag: see mk_split_planes. */
 int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
                         float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
-                        int bord_h, int bord_w, int bord_m, mk_stream_t stream);
+                        int bord_h, int bord_w, int bord_m, int* sat_flag, mk_stream_t stream);
 
 /* Non-causal multi-head attention, softmax(q k^T) v with head_dim 64 (layers/attention.py:53-59),
  * flash style (the ntok x ntok matrix is never materialised).  q/k/vt as written by mk_gemm_qkv;
@@ -188,32 +189,40 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
 /* The same convolution with SPLIT operands -- fp32-grade products on the 16-bit matrix cores (the reference runs its heads in
  * fp32, mickey_extractor.py:53-56; the fp32-input MFMA is 1/16 of the 16-bit rate).  Activations and weights are each held as
  * two fp16 planes, x * s = hi + lo (22 mantissa bits; s a power of two that keeps lo out of fp16's subnormals), and every
- * product is evaluated as lo.hi + hi.lo + hi.hi: three sweeps of the plain kernel's K loop with fp32 accumulation.
- *   in1_hi / in1_lo, in2_hi / in2_lo: bordered fp16 feature maps (mk_split_planes of the fp32 maps, scale s_a);
- *   W: fp16 [Cout, 3 K], K = 9 C1 + C2, = [W_hi | W_lo | W_hi] of the BatchNorm-folded weights times s_w (the HI weights meet
- *      the LO activations in sweep 0); an identity shortcut is passed as in2 = the block input with identity columns in W;
+ * product is evaluated as hi.hi + lo.hi + hi.lo with fp32 accumulation.  SHARED operands (round 6): a K step of 32 stages the
+ * four planes a_hi, a_lo, w_hi, w_lo ONCE in LDS (one 128-byte row = 32 hi | 32 lo elements) and issues the three MFMA sets from
+ * those fragments -- L2 -> LDS bytes and LDS fragment reads per product are 2/3 of three plain sweeps'.
+ *   in1_hi / in1_lo, in2_hi / in2_lo: bordered fp16 feature maps (mk_split_planes of the fp32 maps, scale s_a); the two planes
+ *      of a source must lie within 2 GiB of each other (one allocation);
+ *   W: fp16 [Cout, 2 K], K = 9 C1 + C2: the BatchNorm-folded weights times s_w as INTERLEAVED planes -- for every block of 32
+ *      K columns, 32 hi values then 32 lo values (weights.split_conv_weight); an identity shortcut is passed as in2 = the
+ *      block input with identity columns in W;
  *   out: out_lo == NULL: fp32 [.., Cout], dense rows or (out_bordered) a bordered feature map; out_lo != NULL: the result
  *      goes out as the NEXT split conv's operand planes instead, fp16 out = hi, out_lo = lo of result * plane_scale (same
- *      layout; saturating at fp16's largest finite value); acc_scale = 1 / (s_a s_w), applied to the accumulators before
- *      bias / activation. */
+ *      layout; saturating at fp16's largest finite value, NaN kept); acc_scale = 1 / (s_a s_w), applied to the accumulators
+ *      before bias / activation;
+ *   sat_flag: NULL, or a zero-initialised int in device memory that gets bit 0 set when a plane value had to be clamped
+ *      (|result * plane_scale| > 65504) or was NaN -- per call, so that two models / streams never share a word.
+ *   C1, C2 % 32 == 0. */
 int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
                      long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
                      long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
-                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, mk_stream_t stream);
+                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, int* sat_flag, mk_stream_t stream);
 
-/* fp32 [rows, cols] (row stride ld_src) -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504),
- * each [rows, cols] with row stride ld_dst.  cols, ld_src, ld_dst % 4 == 0. */
+/* fp32 [rows, cols] (row stride ld_src) -> fp16 planes hi = rn16(x scale), lo = rn16(x scale - hi) (saturating at +-65504, NaN
+ * kept), each [rows, cols] with row stride ld_dst.  cols, ld_src, ld_dst % 4 == 0.  sat_flag: NULL, or a zero-initialised
+ * device int that gets bit 0 set when a value was clamped or NaN (activations are held as x * 64: |x| > 1023 saturates). */
 int mk_split_planes(const float* src, long long rows, int cols, long long ld_src, float scale, void* hi, void* lo,
-                    long long ld_dst, mk_stream_t stream);
+                    long long ld_dst, int* sat_flag, mk_stream_t stream);
 
 /* Grouped GEMM with SPLIT operands (the small linears of the heads' attention layers in AMD.HEADS_DTYPE: split; reference
  * att_layers/transformer_utils.py:51-66 runs them in fp32): out[g] = act(A[g] W[g]^T + bias[g]) with A = (A_hi + A_lo) / s_a
- * as fp16 planes [M, lda] and W fp16 [N, 3 K] = [W_hi | W_lo | W_hi] of the weights times s_w -- lo.hi + hi.lo + hi.hi on the
- * 16-bit matrix cores, fp32 accumulation (as mk_conv3x3_split).  out: fp32 [M, ldc], or with out_lo != NULL the (hi, lo)
- * planes of result * plane_scale.  K % 64 == 0. */
+ * as fp16 planes [M, lda] (within 2 GiB of each other) and W fp16 [N, 2 K] = the interleaved (32 hi | 32 lo) planes of the
+ * weights times s_w -- hi.hi + lo.hi + hi.lo on the 16-bit matrix cores from operands staged once, fp32 accumulation (as
+ * mk_conv3x3_split).  out: fp32 [M, ldc], or with out_lo != NULL the (hi, lo) planes of result * plane_scale.  K % 32 == 0. */
 int mk_gemm_grouped_split(const void* A_hi, const void* A_lo, int lda, long long strideA, const void* W, int ldw, long long strideW,
                           const float* bias, long long strideBias, void* out, void* out_lo, int ldc, long long strideOut, int groups,
-                          int M, int N, int K, int act, float acc_scale, float plane_scale, mk_stream_t stream);
+                          int M, int N, int K, int act, float acc_scale, float plane_scale, int* sat_flag, mk_stream_t stream);
 
 /* Start of Transformer_self_att (att_layers/transformer.py:92-95): xs = x + pe (fp32 stream) and an
  * lp copy into columns [0,C) of a [rows, ld_cat] buffer.  x lp [G][rows, C]; pe fp32 [npix, C] or NULL. */

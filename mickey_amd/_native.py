@@ -35,13 +35,13 @@ SIGNATURES = {
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
     "mk_layernorm": ("i", "pippfpiipiiiiiiiiiip"),
-    "mk_layernorm_planes": ("i", "pippfppifpiiiiiiiiip"),
+    "mk_layernorm_planes": ("i", "pippfppifpiiiiiiiiipp"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_bordered_rows": ("l", "iii"),
     "mk_conv3x3": ("i", "pliplipilplplpiliiiiiiip"),
-    "mk_conv3x3_split": ("i", "pplipplipilplppiliiiiiiffp"),
-    "mk_split_planes": ("i", "plilfpplp"),
-    "mk_gemm_grouped_split": ("i", "ppilpilplppiliiiiiffp"),
+    "mk_conv3x3_split": ("i", "pplipplipilplppiliiiiiiffpp"),
+    "mk_split_planes": ("i", "plilfpplpp"),
+    "mk_gemm_grouped_split": ("i", "ppilpilplppiliiiiiffpp"),
     "mk_posenc_add": ("i", "ppppiiiiiip"),
     "mk_linattn_work_floats": ("l", "iiii"),
     "mk_linattn_kv": ("i", "pppiiiip"),
@@ -75,7 +75,6 @@ DEV_SIGNATURES = {
     "mk_sinkhorn_set_group": ("i", "i"),
     "mk_dual_softmax_set_chunks": ("i", "i"),
     "mk_exprace_set_mode": ("i", "i"),
-    "mk_split_watch_saturation": ("i", "p"),
 }
 
 _lib = None

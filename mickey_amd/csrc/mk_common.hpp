@@ -37,15 +37,17 @@ void mk_set_error(const char* fmt, ...);
 
 namespace mk {
 
-// Split-operand planes (x * scale = hi + lo in fp16) saturate at fp16's largest finite value.  A watcher word registered through
-// mk_split_watch_saturation (mickey_hip_dev.h; null = nobody watches, the default: no per-element work) gets bit 0 set by any
-// kernel that had to clamp -- NaN inputs included (fminf / fmaxf drop them) -- so that a head activation beyond the planes' range
-// (|x| > 1023 at the activation scale 64) cannot pass silently.
-extern int* g_sat_flag;   // host side: the registered device word (mk_norm.hip)
+// Split-operand planes (x * scale = hi + lo in fp16) saturate at fp16's largest finite value; a NaN stays a NaN (both planes), so
+// that a non-finite head activation reaches the outputs and the callers' finite checks.  flag: the per-call watcher word of the
+// plane-writing entry points (mickey_hip.h: sat_flag; null = nobody watches: no per-element work) gets bit 0 set by any kernel
+// that had to clamp or met a NaN -- a head activation beyond the planes' range (|x| > 1023 at the activation scale 64) cannot
+// pass silently.  The word is read first: once set, no further atomics (widespread saturation does not serialise on one address).
 __device__ __forceinline__ float sat16(float sv, int* flag) {
   const float c = fminf(fmaxf(sv, -65504.f), 65504.f);
-  if (flag && c != sv) atomicOr(flag, 1);
-  return c;
+  if (flag && !(c == sv)) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
+  }
+  return sv != sv ? sv : c;
 }
 
 // ---- MFMA wrappers: 16-bit operand type selects the instruction ---------------------------------

@@ -30,7 +30,10 @@ namespace {
 // Two LDS stages, the LDS-DMA of the next K tile is issued before the MFMAs of the current one, one barrier per K tile.
 // WMF = 16-row fragments per wave: 4 -> 128x128 tiles; 2 -> 64x128 tiles (48 KiB of LDS, 3 workgroups per CU) for problems
 // whose 128x128 tiling would leave CUs without work (proj / fc2 of a single image pair: 248 -> 488 workgroups).
-template <typename T, int AMODE, int WMF>
+// SP: split operands staged once (mk_gemm_common.hpp, GemmParams): a K tile is 32 contraction columns, its LDS rows hold
+// [32 hi | 32 lo] -- sub-step 0 reads the HI fragments of W and A, sub-step 1 the LO fragments, and the three products
+// hi.hi, lo.hi, hi.lo come from those registers (the plain kernel's two sub-steps are the two K halves of a 64-column tile).
+template <typename T, int AMODE, int WMF, bool SP = false>
 __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   using V8 = typename Lp<T>::V8;
   constexpr int NWM = 2, NWN = 2;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   // xcd_remap keeps the tiles that one XCD works on at any time adjacent (same A panel / neighbouring W panels in its L2)
   const int id = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-  Stager<T, AMODE, NW, AJ, WJ> st;
+  Stager<T, AMODE, NW, AJ, WJ, SP> st;
   st.init(p, g, m0, n0, wave, lane);
   st.issue(p, smem, smem + A_BYTES, 0);
   if (NS == 3 && nk > 1) st.issue(p, smem + STAGE_BYTES, smem + STAGE_BYTES + A_BYTES, 1);
@@ -84,35 +87,59 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
     const char* sW = sA + A_BYTES;
     cur = cur + 1 == NS ? 0 : cur + 1;
     nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    if constexpr (SP) {
+      V8 wf[2][4], xf[2][WMF];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V8 wf[4], xf[WMF];
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rw = wn * 64 + i * 16 + fr;
-        wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+        for (int i = 0; i < 4; ++i) {
+          const int rw = wn * 64 + i * 16 + fr;
+          wf[ks][i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+          const int rx = wm * (WMF * 16) + i * 16 + fr;
+          xf[ks][i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+        }
       }
 #pragma unroll
-      for (int i = 0; i < WMF; ++i) {
-        const int rx = wm * (WMF * 16) + i * 16 + fr;
-        xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+      for (int pr = 0; pr < 3; ++pr) {   // hi.hi, W_lo . A_hi, W_hi . A_lo
+#pragma unroll
+        for (int mi = 0; mi < WMF; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[pr == 1][ni], xf[pr == 2][mi], acc[mi][ni]);
       }
+    } else {
 #pragma unroll
-      for (int mi = 0; mi < WMF; ++mi)
+      for (int ks = 0; ks < 2; ++ks) {
+        V8 wf[4], xf[WMF];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+        for (int i = 0; i < 4; ++i) {
+          const int rw = wn * 64 + i * 16 + fr;
+          wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+          const int rx = wm * (WMF * 16) + i * 16 + fr;
+          xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, ks * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int mi = 0; mi < WMF; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Lp<T>::mma16(wf[ni], xf[mi], acc[mi][ni]);
+      }
     }
   }
   epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g, lnp);
 }
 
-template <typename T, int AMODE, int WMF>
+template <typename T, int AMODE, int WMF, bool SP = false>
 int launch_small(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 32 * WMF;
   constexpr int LDS = (WMF == 2 ? 3 : 2) * (BM + 128) * 128 + BM * 8;   // the stages + the folded LayerNorm's row parameters
   static bool attr_done = false;  // benign race: the attribute call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -120,7 +147,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
     attr_done = true;
   }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, SP>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -140,8 +167,10 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   bool big = p.N >= 256 && big_tiles >= 192;
   // the 256x256 kernels address operands with 32-bit element offsets and run a software pipeline of >= 2 K stages
   // (byte offsets of 16-bit elements in 32 bits: < 2^31 elements)
-  const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
-                    (AMODE == A_DENSE || bordered_rows(p.M / (p.H * p.Wd), p.H, p.Wd) * (p.C1 > p.C2 ? p.C1 : p.C2) < (1ll << 31));
+  // (split operands: the byte offset of a chunk's plane rides in the same 32 bits)
+  const long long plmax = p.npass > 1 ? (long long)max(max(p.pl1[0], p.pl1[1]), max(p.pl2[0], p.pl2[1])) / 2 : 0;
+  const bool k_ok = p.K >= 2 * BK && (long long)p.M * p.lda + plmax < (1ll << 31) && (long long)p.N * p.ldw < (1ll << 31) &&
+                    (AMODE == A_DENSE || bordered_rows(p.M / (p.H * p.Wd), p.H, p.Wd) * (p.C1 > p.C2 ? p.C1 : p.C2) + plmax < (1ll << 31));
   const bool ln_fold = p.ln_stats || p.xh;
   if (dtype == MK_F32) {   // exact parity mode: one plain schedule, LayerNorm as its own kernel
     MK_CHECK_ARG(!ln_fold, "gemm: the folded-LayerNorm epilogues exist for 16-bit operands only");
@@ -154,6 +183,8 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   // 128x128 tiles fill a 256-CU part (2 workgroups per CU) from 512 tiles on; below that 64-row tiles double the count
   const long long small_tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * groups;
   const bool half_rows = g_schedule == 2 || (g_schedule != 1 && g_half_rows && small_tiles < 2 * num_cus() && p.M > 64);
+  if (p.npass > 1)   // split operands (fp16 planes)
+    return half_rows ? launch_small<_Float16, AMODE, 2, true>(p, groups, st) : launch_small<_Float16, AMODE, 4, true>(p, groups, st);
   if (half_rows) return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 2>(p, groups, st) : launch_small<_Float16, AMODE, 2>(p, groups, st);
   return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 4>(p, groups, st) : launch_small<_Float16, AMODE, 4>(p, groups, st);
 }
@@ -375,49 +406,66 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }  // namespace
 
 int mk_split_planes(const float* src, long long rows, int cols, long long ld_src, float scale, void* hi, void* lo,
-                    long long ld_dst, mk_stream_t stream) {
+                    long long ld_dst, int* sat_flag, mk_stream_t stream) {
   MK_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= cols &&
                    ld_dst >= cols, "mk_split_planes: cols / ld_src / ld_dst must be multiples of 4 and ld >= cols");
   MK_CHECK_ARG((((uintptr_t)src | (uintptr_t)hi * 2 | (uintptr_t)lo * 2) & 15) == 0, "mk_split_planes: src must be 16-byte, planes 8-byte aligned");
   const long long n4 = rows * (cols / 4);
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, cols / 4,
-                     ld_src / 4, scale, (uint2*)hi, (uint2*)lo, ld_dst / 4, mk::g_sat_flag);
+                     ld_src / 4, scale, (uint2*)hi, (uint2*)lo, ld_dst / 4, sat_flag);
   MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+// the two planes of a split source: base = the lower address, pl = byte offsets of (hi, lo) from it (< 2 GiB)
+static int split_source(const void* hi, const void* lo, const void*& base, unsigned (&pl)[2], const char* who) {
+  const uintptr_t h = (uintptr_t)hi, l = (uintptr_t)lo, b = h < l ? h : l;
+  MK_CHECK_ARG((h - b) < (1ull << 31) && (l - b) < (1ull << 31) && ((h | l) & 15) == 0,
+               "%s: the (hi, lo) planes of a source must be 16-byte aligned and lie within 2 GiB of each other", who);
+  base = (const void*)b;
+  pl[0] = (unsigned)(h - b);
+  pl[1] = (unsigned)(l - b);
   return MK_OK;
 }
 
 int mk_gemm_grouped_split(const void* A_hi, const void* A_lo, int lda, long long strideA, const void* W, int ldw, long long strideW,
                           const float* bias, long long strideBias, void* out, void* out_lo, int ldc, long long strideOut, int groups,
-                          int M, int N, int K, int act, float acc_scale, float plane_scale, mk_stream_t stream) {
+                          int M, int N, int K, int act, float acc_scale, float plane_scale, int* sat_flag, mk_stream_t stream) {
   GemmParams p = {};
-  p.A = A_hi; p.A_lo = A_lo; p.W = W; p.M = M; p.N = N; p.K = 3 * K; p.lda = lda; p.ldw = ldw;
+  MK_CHECK_ARG(A_hi && A_lo, "mk_gemm_grouped_split: null plane");
+  if (int e = split_source(A_hi, A_lo, p.A, p.pl1, "mk_gemm_grouped_split")) return e;
+  p.W = W; p.M = M; p.N = N; p.K = 2 * K; p.lda = lda; p.ldw = ldw;
   p.npass = 3; p.acc_scale = acc_scale;
   p.strideA_g = strideA; p.strideW_g = strideW; p.strideBias_g = strideBias; p.strideOut_g = strideOut;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = ldc;
-  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = g_sat_flag; } else { p.out_f32 = (float*)out; }
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = sat_flag; } else { p.out_f32 = (float*)out; }
   if (int e = check_common(p, MK_F16)) return e;
-  MK_CHECK_ARG(A_lo && out && groups > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldc % 4 == 0 && ldc >= N,
-               "mk_gemm_grouped_split: bad args (K must be a multiple of %d)", BK);
+  MK_CHECK_ARG(out && groups > 0 && K % 32 == 0 && lda % 8 == 0 && lda >= K && ldc % 4 == 0 && ldc >= N,
+               "mk_gemm_grouped_split: bad args (K must be a multiple of 32)");
   return launch<A_DENSE>(p, groups, MK_F16, (hipStream_t)stream);
 }
 
 int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in1, int C1, const void* in2_hi, const void* in2_lo,
                      long long stride_in2, int C2, const void* W, int ldw, long long strideW, const float* bias,
                      long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
-                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, mk_stream_t stream) {
+                     int Wd, int act, int out_bordered, float acc_scale, float plane_scale, int* sat_flag, mk_stream_t stream) {
   GemmParams p = {};
-  p.A = in1_hi; p.A_lo = in1_lo; p.A2 = in2_hi; p.A2_lo = in2_lo; p.W = W;
+  MK_CHECK_ARG(in1_hi && in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");
+  if (int e = split_source(in1_hi, in1_lo, p.A, p.pl1, "mk_conv3x3_split")) return e;
+  if (in2_hi) {
+    if (int e = split_source(in2_hi, in2_lo, p.A2, p.pl2, "mk_conv3x3_split")) return e;
+  }
+  p.W = W;
   p.npass = 3; p.acc_scale = acc_scale;
-  p.M = nimg * H * Wd; p.N = Cout; p.K = 3 * (9 * C1 + (in2_hi ? C2 : 0));
+  p.M = nimg * H * Wd; p.N = Cout; p.K = 2 * (9 * C1 + (in2_hi ? C2 : 0));
   p.ldw = ldw; p.strideA_g = stride_in1; p.strideA2_g = stride_in2; p.strideW_g = strideW;
   p.strideBias_g = strideBias; p.strideOut_g = strideOut;
   p.H = H; p.Wd = Wd; p.C1 = C1; p.C2 = in2_hi ? C2 : 0;
   p.epi = MK_EPI_STORE; p.act = act; p.bias = bias; p.ldc = Cout;
-  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = g_sat_flag; } else { p.out_f32 = (float*)out; }
+  if (out_lo) { p.out_lp = out; p.out_lo = out_lo; p.plane_scale = plane_scale; p.sat_flag = sat_flag; } else { p.out_f32 = (float*)out; }
   p.bord_out = out_bordered ? 1 : 0;
   if (int e = check_common(p, MK_F16)) return e;
-  MK_CHECK_ARG(in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");
-  MK_CHECK_ARG(C1 % BK == 0 && (!in2_hi || C2 % BK == 0), "mk_conv3x3_split: channel counts must be multiples of the K tile (%d)", BK);
+  MK_CHECK_ARG(C1 % 32 == 0 && (!in2_hi || C2 % 32 == 0), "mk_conv3x3_split: channel counts must be multiples of 32");
   MK_CHECK_ARG(out && groups > 0 && nimg > 0 && H > 0 && Wd > 0, "mk_conv3x3_split: bad args");
   return launch<A_CONV3>(p, groups, MK_F16, (hipStream_t)stream);
 }

@@ -23,12 +23,13 @@ struct GemmParams {
   // conv geometry
   int H, Wd, C1, C2;   // image grid, channels of source 1 / source 2
   int bord_out;        // conv: the output is written in the bordered layout too (it feeds the next conv)
-  // conv with SPLIT operands (mk_conv3x3_split): x = hi + lo 16-bit planes of activations and weights, the product evaluated
-  // as lo.hi + hi.lo + hi.hi -- npass = 3 sweeps over the same K range (9 C1 + C2 each): sweep 0 reads the LO activation
-  // planes (A_lo, A2_lo), sweeps 1 and 2 the HI planes (A, A2); W holds [W_hi | W_lo | W_hi] along K.  acc_scale undoes the
-  // power-of-two scaling of the planes in the epilogue (1.0f = plain conv: no multiply is issued).
-  const void* A_lo;
-  const void* A2_lo;
+  // SPLIT operands (mk_conv3x3_split, mk_gemm_grouped_split; npass = 3 marks them): x = hi + lo 16-bit planes of activations and
+  // weights, the product evaluated as hi.hi + lo.hi + hi.lo from operands staged ONCE per K step of 32: an LDS row of 128 bytes
+  // holds [32 hi | 32 lo] elements of one operand row, so K (and ldw) count 2 x the contraction length and W is the
+  // interleaved plane layout of mickey_hip.h.  A / A2 point at the LOWER plane of each source, pl1 / pl2 = byte offsets of
+  // (hi, lo) from there (one of each pair is 0; the planes of a source lie within 2 GiB of each other: checked by the entry
+  // points).  acc_scale undoes the power-of-two scaling of the planes in the epilogue.
+  unsigned pl1[2], pl2[2];
   int npass;           // 0 / 1: plain; 3: split operands
   float acc_scale;
   // ... whose output feeds another split conv: written straight as the next conv's operand planes, out_lp = hi, out_lo = lo
@@ -316,14 +317,12 @@ __device__ __forceinline__ int vperm(int t) { return (t & ~12) | ((t & 4) << 1) 
 
 // Per-lane LDS-DMA state of one workgroup tile.  Piece (wave*J + j) is 8 rows x 128 B = 1 KiB of the LDS image; this
 // lane feeds row +(lane>>3), 16-byte chunk lane&7 of it, fetching the XOR-swizzled source chunk.
-template <typename T, int AMODE, int NW, int AJ, int WJ>
+template <typename T, int AMODE, int NW, int AJ, int WJ, bool SP = false>
 struct Stager {
   const T* A;
   const T* A2;
-  const T* Alo;    // split-operand conv: the LO planes (sweep 0)
-  const T* A2lo;
   const T* wrow[WJ];
-  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk); conv: bordered row of the pixel
+  long long aoff[AJ];  // dense: element offset of (row, swizzled chunk) (SP: + the chunk's plane); conv: bordered row of the pixel
   int wave, srow, sp;
 
   __device__ __forceinline__ void init(const GemmParams& p, int g, int m0, int n0, int wave_, int lane) {
@@ -332,8 +331,6 @@ struct Stager {
     sp = lane & 7;
     A = (const T*)p.A + (long long)g * p.strideA_g;
     A2 = p.A2 ? (const T*)p.A2 + (long long)g * p.strideA2_g : nullptr;
-    Alo = p.A_lo ? (const T*)p.A_lo + (long long)g * p.strideA_g : nullptr;
-    A2lo = p.A2_lo ? (const T*)p.A2_lo + (long long)g * p.strideA2_g : nullptr;
     const T* W = (const T*)p.W + (long long)g * p.strideW_g;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -347,58 +344,50 @@ struct Stager {
       const int r = (wave * AJ + j) * 8 + srow;
       int m = m0 + r;
       m = m < p.M ? m : p.M - 1;
-      if (AMODE == A_DENSE) aoff[j] = (long long)m * p.lda + swz8(r, sp) * EPC<T>;
+      const int c = swz8(r, sp);
+      // SP: source chunks 0..3 of an LDS row are 32 elements of the HI plane, 4..7 the same 32 elements of the LO plane
+      if (AMODE == A_DENSE) aoff[j] = SP ? (long long)m * p.lda + (c & 3) * EPC<T> + (long long)(((c >> 2) ? p.pl1[1] : p.pl1[0]) / sizeof(T))
+                                         : (long long)m * p.lda + c * EPC<T>;
       else aoff[j] = bordered_row(m, p.H, p.Wd);
     }
   }
 
   __device__ __forceinline__ void issue(const GemmParams& p, char* sA, char* sW, int kt) const {
-    const int k0 = kt * KT<T>;
+    const int k0 = kt * KT<T>;                     // W columns of this stage
+    const int ka = SP ? kt * (KT<T> / 2) : k0;     // contraction index of its A columns
     if (AMODE == A_DENSE) {
-      // split operands (mk_gemm_grouped_split): three sweeps over the K columns of A -- sweep 0 reads the LO plane
-      const T* const ah = A;
-      const T* const al = Alo;
-      const T* base = ah;
-      int kk = k0;
-      if (p.npass > 1) {
-        const int kp = p.K / 3, sweep = k0 / kp;
-        kk = k0 - sweep * kp;
-        base = sweep == 0 ? al : ah;
-      }
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) glds16(base + aoff[j] + kk, sA + (wave * AJ + j) * 1024);
+      for (int j = 0; j < AJ; ++j) glds16(A + aoff[j] + ka, sA + (wave * AJ + j) * 1024);
     } else {
-      // wave-uniform: which sweep (split operands) / source / tap does this K tile belong to
+      // wave-uniform: which source / tap does this K tile belong to
       const int kc = 9 * p.C1;
-      int kk = k0;
-      bool lo = false;
-      if (p.npass > 1) {
-        const int kp = kc + p.C2, sweep = k0 / kp;
-        kk = k0 - sweep * kp;
-        lo = sweep == 0;
-      }
-      // (the four plane pointers as values first: a select between two MEMBER loads keeps the whole Stager in scratch)
-      const T* const s1h = A;
-      const T* const s1l = Alo;
-      const T* const s2h = A2;
-      const T* const s2l = A2lo;
+      // (the source pointers as values first: a select between two MEMBER loads keeps the whole Stager in scratch)
+      const T* const s1 = A;
+      const T* const s2 = A2;
       const T* src;
       int cs, c0, shift = 0;   // shift: the tap in bordered rows (out-of-image taps land on zero border rows)
-      if (kk < kc) {
-        const int tap = kk / p.C1;
-        c0 = kk - tap * p.C1;
+      unsigned plh, pll;
+      if (ka < kc) {
+        const int tap = ka / p.C1;
+        c0 = ka - tap * p.C1;
         shift = (tap / 3 - 1) * (p.Wd + 1) + tap % 3 - 1;
-        src = lo ? s1l : s1h;
+        src = s1;
         cs = p.C1;
+        plh = p.pl1[0];
+        pll = p.pl1[1];
       } else {
-        c0 = kk - kc;
-        src = lo ? s2l : s2h;
+        c0 = ka - kc;
+        src = s2;
         cs = p.C2;
+        plh = p.pl2[0];
+        pll = p.pl2[1];
       }
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
         const int r = (wave * AJ + j) * 8 + srow;
-        glds16(src + (aoff[j] + shift) * cs + c0 + swz8(r, sp) * EPC<T>, sA + (wave * AJ + j) * 1024);
+        const int c = swz8(r, sp);
+        if (SP) glds16(src + (aoff[j] + shift) * cs + c0 + (c & 3) * EPC<T> + (long long)(((c >> 2) ? pll : plh) / sizeof(T)), sA + (wave * AJ + j) * 1024);
+        else glds16(src + (aoff[j] + shift) * cs + c0 + c * EPC<T>, sA + (wave * AJ + j) * 1024);
       }
     }
 #pragma unroll

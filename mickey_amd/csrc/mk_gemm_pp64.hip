@@ -33,9 +33,21 @@ namespace {
 // turned into LDS entries behind the first stage's wait.  What a tile boundary still costs is the epilogue itself; gone are
 // the workgroup launch, the argument loads, the address set-up and the L2 / HBM round trip to the first fragments (2-3 us per
 // ~35-us tile, LABNOTES R4.12).  Tile order, summation order and every epilogue are the non-persistent kernel's: bit-identical.
-template <typename T, int AMODE, int KIND, bool PERSIST = false>
+//
+// SP (round 6): SPLIT operands staged once (GemmParams; mk_conv3x3_split / mk_gemm_grouped_split).  A stage is 32 contraction
+// columns; its 128-byte LDS rows hold [32 hi | 32 lo] of an operand row, so the K = 32 sub-step h = 0 reads HI fragments and
+// h = 1 LO fragments, and a stage is THREE (L, C) slot pairs instead of two:
+//     L0: W_hi, A_hi fragments (12 reads)     C0: W_hi . A_hi
+//     L1: W_lo fragments (4 reads) + W DMA    C1: W_lo . A_hi
+//     L2: A_lo fragments (8 reads)            C2: W_hi . A_lo  + A DMA of stage kt+2 between the MFMAs
+// -- 96 MFMAs per wave on the 8 DMA pieces and 24 fragment reads that 64 MFMAs of a plain stage (or of one of the three
+// sweeps this replaces) take.  Ring hand-over is the plain kernel's with "last reader" = L2 for A and L1 for W: row g's
+// A(kt+2) pieces go out in its C2(kt) slot, one barrier behind its L2(kt); the same counted waits at the end of a stage.
+template <typename T, int AMODE, int KIND, bool PERSIST = false, bool SP = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
   static_assert(!PERSIST || AMODE == A_DENSE, "the persistent tile loop is built for dense operands");
+  static_assert(!SP || (KIND == 0 && !PERSIST && sizeof(T) == 2), "split operands: plain epilogues, one tile per workgroup");
+  constexpr int BKA = SP ? BK / 2 : BK;   // contraction columns of A per stage
   using V8 = typename Lp<T>::V8;
   constexpr int WMF = 8, BM = 256, BN = 256;
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;   // 64 KiB per stage
@@ -92,13 +104,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       const int ra = wm * 128 + (wn * 4 + j) * 8 + srow;
       int m = mm0 + ra;
       m = m < p.M ? m : p.M - 1;
+      // SP: source chunks 0..3 of an LDS row come from the HI plane, 4..7 (the same 32 columns) from the LO plane
+      const int c = swz8(ra, sp);
+      const unsigned cc = SP ? (unsigned)(c & 3) : (unsigned)c;
+      const bool lo = SP && (c >> 2) != 0;   // (selects, not an indexed load: a per-lane index into the kernel arguments makes them vector loads)
+      const unsigned pb1 = !SP ? 0u : (lo ? p.pl1[1] : p.pl1[0]), pb2 = !SP ? 0u : (lo ? p.pl2[1] : p.pl2[0]);
       if (AMODE == A_DENSE) {
-        aoff[j] = ((unsigned)m * (unsigned)p.lda + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
+        aoff[j] = ((unsigned)m * (unsigned)p.lda + cc * 8) * (unsigned)sizeof(T) + pb1;
         aoff2[j] = 0;
       } else {   // the pixel's row in the bordered feature maps (mk_common.hpp): a tap is a wave-uniform shift of it
         const unsigned br = (unsigned)bordered_row(m, p.H, p.Wd);
-        aoff[j] = (br * (unsigned)p.C1 + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
-        aoff2[j] = (br * (unsigned)p.C2 + swz8(ra, sp) * 8) * (unsigned)sizeof(T);
+        aoff[j] = (br * (unsigned)p.C1 + cc * 8) * (unsigned)sizeof(T) + pb1;
+        aoff2[j] = (br * (unsigned)p.C2 + cc * 8) * (unsigned)sizeof(T) + pb2;
       }
     }
   };
@@ -111,40 +128,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // conv: A stages are issued in K order (0, 1, 2, ...), so where the NEXT stage reads -- source, 3x3 tap, first channel,
   // folded into one wave-uniform base pointer -- is running scalar state, advanced once per stage.  K = 9 taps x C1 channels of source 1, then C2 channels of source 2
   // (the 1x1 shortcut) at the pixel itself.
-  // Split operands (p.npass == 3, mk_conv3x3_split): the K range is swept three times -- sweep 0 over the LO activation
-  // planes, sweeps 1 and 2 over the HI planes (W holds [W_hi | W_lo | W_hi] along K, so the W side just keeps streaming).
-  const bool split = AMODE != A_DENSE && p.npass > 1;
-  const T* Acur = split ? (const T*)p.A_lo + (long long)g * p.strideA_g : A;
-  const T* A2cur = split && p.A2_lo ? (const T*)p.A2_lo + (long long)g * p.strideA2_g : A2;
-  const int ntap = A2 ? 10 : 9;   // K segments of one sweep: nine taps (+ the shortcut source)
-  const T* cbase = AMODE == A_DENSE ? A : Acur - (long long)(p.Wd + 2) * p.C1;   // tap (-1, -1), channel 0
+  const int ntap = A2 ? 10 : 9;   // K segments: nine taps (+ the shortcut source)
+  const T* cbase = AMODE == A_DENSE ? A : A - (long long)(p.Wd + 2) * p.C1;   // tap (-1, -1), channel 0
   int cleft = p.C1, ctap = 0;
   auto conv_advance = [&]() {
-    cleft -= BK;
+    cleft -= BKA;
     const bool wrap = cleft == 0;
     ctap += wrap ? 1 : 0;
-    if (wrap && ctap == ntap) {   // end of a sweep (only the split form goes on from here): HI planes from now on
-      ctap = 0;
-      Acur = A;
-      A2cur = A2;
-    }
     const int ty = (ctap * 11) >> 5, tx = ctap - 3 * ty;   // ctap / 3, ctap % 3 for 0 <= ctap < 9
-    const T* tapbase = ctap < 9 ? Acur + (long long)((ty - 1) * (p.Wd + 1) + tx - 1) * p.C1 : A2cur;
-    cbase = wrap ? tapbase : cbase + BK;
+    const T* tapbase = ctap < 9 ? A + (long long)((ty - 1) * (p.Wd + 1) + tx - 1) * p.C1 : A2;
+    cbase = wrap ? tapbase : cbase + BKA;
     cleft = wrap ? (ctap < 9 ? p.C1 : p.C2) : cleft;
   };
   auto dma_a1 = [&](int s, int j) {
     char* dst = smem + (s & 1) * STAGE_BYTES + (wm * 16 + wn * 4 + j) * 1024;
     if (AMODE == A_DENSE) {
-      if constexpr (KIND == 0) {   // plain kernel: may run with split operands (mk_gemm_grouped_split): sweep 0 reads the LO plane
-        if (p.npass > 1) {
-          const int nkp = nk / 3, sweep = s >= 2 * nkp ? 2 : (s >= nkp ? 1 : 0);
-          const T* base = sweep == 0 ? (const T*)p.A_lo + (long long)g * p.strideA_g : A;
-          glds16_sv(base + (s - sweep * nkp) * BK, aoff[j], dst);
-          return;
-        }
-      }
-      glds16_sv(A + s * BK, aoff[j], dst);
+      glds16_sv(A + s * BKA, aoff[j], dst);
     } else {
       glds16_sv(cbase, ctap < 9 ? aoff[j] : aoff2[j], dst);   // the caller advances behind the 4th piece
     }
@@ -166,19 +165,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
     fr = lane & 15;
     fg = lane >> 4;
   };
-  auto load_frags = [&](V8* wf, V8* xf, int par, int h) {
-    const char* sA = smem + par * STAGE_BYTES;
-    const char* sW = sA + A_BYTES;
+  auto load_w = [&](V8* wf, int par, int h) {
+    const char* sW = smem + par * STAGE_BYTES + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rw = wn * 64 + i * 16 + fr;
       wf[i] = *(const V8*)(sW + rw * 128 + swz8(rw, h * 4 + fg) * 16);
     }
+  };
+  auto load_x = [&](V8* xf, int par, int h) {
+    const char* sA = smem + par * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < WMF; ++i) {
       const int rx = wm * 128 + i * 16 + fr;
       xf[i] = *(const V8*)(sA + rx * 128 + swz8(rx, h * 4 + fg) * 16);
     }
+  };
+  auto load_frags = [&](V8* wf, V8* xf, int par, int h) {
+    load_w(wf, par, h);
+    load_x(xf, par, h);
   };
   f32x4 acc[WMF][4];
   auto zero_acc = [&]() {
@@ -221,11 +226,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
   V8 wf[4], xf[WMF];
+  V8 wfl[SP ? 4 : 1];   // SP: the W_lo fragments (wf = W_hi stays live through the stage)
   // one K = 64 stage of wave-row 0 / 1; NEXT1: stage kt+1 exists, NEXT2: stage kt+2 exists (compile time: the slots stay
   // single basic blocks, so the DMA pieces can be pinned between the MFMAs)
   // sw / sa: the stage whose W / A pieces this stage issues -- kt + 1 / kt + 2, or (PERSIST, last two stages of a tile, woff /
   // aoff already re-pointed) stage 0 of the workgroup's NEXT tile; nk is even there, so the ring half is the same either way
   auto stage0 = [&](int kt, auto next1, auto next2, int sw, int sa, auto first) {
+    if constexpr (SP) {
+      bar();                      // slot 6kt
+      load_frags(wf, xf, kt & 1, 0);
+      bar();                      // slot 6kt+1
+      mfma32(wf, xf, No{}, 0, first);     // W_hi . A_hi
+      bar();                      // slot 6kt+2
+      load_w(wfl, kt & 1, 1);
+      if constexpr (decltype(next1)::value) dma_w(sw);
+      bar();                      // slot 6kt+3
+      mfma32(wfl, xf, No{}, 0, No{});     // W_lo . A_hi
+      bar();                      // slot 6kt+4
+      load_x(xf, kt & 1, 1);
+      bar();                      // slot 6kt+5
+      mfma32(wf, xf, next2, sa, No{});    // W_hi . A_lo
+      if constexpr (decltype(next2)::value)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     bar();   // slot 4kt
     load_frags(wf, xf, kt & 1, 0);
     if constexpr (decltype(next1)::value) dma_w(sw);
@@ -241,6 +267,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto stage1 = [&](int kt, auto next1, auto next2, int sw, int sa, auto first) {
+    if constexpr (SP) {
+      bar();                      // slot 6kt+1
+      load_frags(wf, xf, kt & 1, 0);
+      bar();                      // slot 6kt+2
+      mfma32(wf, xf, No{}, 0, first);
+      bar();                      // slot 6kt+3
+      load_w(wfl, kt & 1, 1);
+      if constexpr (decltype(next1)::value) dma_w(sw);
+      bar();                      // slot 6kt+4
+      mfma32(wfl, xf, No{}, 0, No{});
+      bar();                      // slot 6kt+5
+      load_x(xf, kt & 1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
+      bar();                      // slot 6kt+6
+      mfma32(wf, xf, next2, sa, No{});
+      return;
+    }
     bar();                      // slot 4kt+1
     load_frags(wf, xf, kt & 1, 0);
     if constexpr (decltype(next1)::value) dma_w(sw);
@@ -385,19 +428,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   }
 }
 
-template <typename T, int AMODE, int KIND, bool PERSIST>
+template <typename T, int AMODE, int KIND, bool PERSIST, bool SP = false>
 int launch_k2(const GemmParams& p, int groups, hipStream_t st, int band_m, int grid) {
   constexpr int LDS = 2 * 512 * 128 + 256 * 8 + (PERSIST && KIND == 1 ? 16384 : 0);   // two stages + the folded LayerNorm's row parameters (+ the statistics' staging area)
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, KIND, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND, PERSIST>), dim3(grid, groups, 1), dim3(512), LDS, st, p, band_m);
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP>), dim3(grid, groups, 1), dim3(512), LDS, st, p, band_m);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -410,6 +453,9 @@ int launch_k(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   // traffic and +2.6 % on fc2 (profiles/r04j_gemm_order.txt); wider outputs keep bands of 8 m-tiles (n-groups there cut the
   // traffic as much and cost 1-6 % of time)
   if (band_m == 0) band_m = (AMODE == A_DENSE && ntn <= 4) ? -4 : 8;
+  if constexpr (KIND == 0 && sizeof(T) == 2 && std::is_same<T, _Float16>::value) {
+    if (p.npass > 1) return launch_k2<T, AMODE, 0, false, true>(p, groups, st, band_m, ntm * ntn);   // split operands
+  }
   if constexpr (AMODE == A_DENSE && KIND != 0) {   // (KIND 0: the plain epilogues -- head linears, patch embed of the unfolded
                                                     // mode: not the encoder's hot launches; its eight inlined variants spill in the loop)
     // persistent tile loop: one workgroup per CU (a multiple of 8: a workgroup keeps its XCD) walking a continuous K stream over

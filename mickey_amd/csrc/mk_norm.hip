@@ -7,10 +7,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-namespace mk {
-int* g_sat_flag = nullptr;   // mk_split_watch_saturation
-}
-
 namespace {
 using namespace mk;
 
@@ -324,15 +320,11 @@ extern "C" {
 
 int mk_version(void) { return 100; }
 
-int mk_split_watch_saturation(int* device_flag) {
-  mk::g_sat_flag = device_flag;
-  return MK_OK;
-}
 const char* mk_last_error(void) { return g_err; }
 
 static int layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, void* out, int ldo, int out_is_f32,
                             float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
-                            int bord_w, int bord_m, int dtype, void* out_lo, float plane_scale, mk_stream_t stream) {
+                            int bord_w, int bord_m, int dtype, void* out_lo, float plane_scale, int* sat_flag, mk_stream_t stream) {
   MK_CHECK_ARG(x && w && b && (out || resid), "mk_layernorm: null pointer");
   MK_CHECK_ARG(bord_h == 0 || (bord_h > 0 && bord_w > 0 && bord_m > 0 && bord_m % (bord_h * bord_w) == 0 && rows_out % bord_m == 0),
                "mk_layernorm: bordered output needs rows_out = k * bord_m, bord_m = nimg * bord_h * bord_w");
@@ -344,7 +336,7 @@ static int layernorm_launch(const float* x, int ldx, const float* w, const float
     dim3 gridn((rows_out + 8 * LNN_TRIPS - 1) / (8 * LNN_TRIPS));
 #define MK_LNN(T_)                                                                                                         \
   hipLaunchKernelGGL((layernorm_narrow_kernel<T_>), gridn, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, mk::g_sat_flag)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, sat_flag)
     if (dtype == MK_BF16) MK_LNN(__bf16);
     else if (dtype == MK_F16) MK_LNN(_Float16);
     else MK_LNN(float);
@@ -355,7 +347,7 @@ static int layernorm_launch(const float* x, int ldx, const float* w, const float
   dim3 grid((rows_out + 4 * LN_RPW - 1) / (4 * LN_RPW));
 #define MK_LN(T_, V_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<T_, V_>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, eps, out, ldo, \
-                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, mk::g_sat_flag)
+                     out_is_f32, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w, bord_m, out_lo, plane_scale, sat_flag)
   if (dtype == MK_BF16) {
     if (D <= 1024) MK_LN(__bf16, 4); else MK_LN(__bf16, LN_MAXV);
   } else if (dtype == MK_F16) {
@@ -372,15 +364,15 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                  float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
                  int bord_w, int bord_m, int dtype, mk_stream_t stream) {
   return layernorm_launch(x, ldx, w, b, eps, out, ldo, out_is_f32 ? 1 : 0, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows,
-                          bord_h, bord_w, bord_m, dtype, nullptr, 1.0f, stream);
+                          bord_h, bord_w, bord_m, dtype, nullptr, 1.0f, nullptr, stream);
 }
 
 int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
                         float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
-                        int bord_h, int bord_w, int bord_m, mk_stream_t stream) {
+                        int bord_h, int bord_w, int bord_m, int* sat_flag, mk_stream_t stream) {
   MK_CHECK_ARG(out_hi && out_lo, "mk_layernorm_planes: null plane pointer");
   return layernorm_launch(x, ldx, w, b, eps, out_hi, ldo, 2, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w,
-                          bord_m, MK_F32, out_lo, plane_scale, stream);
+                          bord_m, MK_F32, out_lo, plane_scale, sat_flag, stream);
 }
 
 int mk_im2col_patch14(const float* img, long long stride_img, long long stride_ch, int stride_row, int nimg, int gh,

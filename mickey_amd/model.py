@@ -59,7 +59,7 @@ def resolve_heads_dtype(cfg, encoder_dtype):
 def resolve_heads_split(cfg):
     """AMD.HEADS_DTYPE: split -- the reference's precision split (fp32 heads behind a 16-bit encoder, mickey_extractor.py:49-56)
     at 16-bit matrix-core speed: head activations, LayerNorms and the small linears as in the fp32 mode, the 3x3
-    convolutions (99 % of the heads' flops) as three fp16 MFMA passes over hi / lo operand planes (mk_conv3x3_split)."""
+    convolutions (99 % of the heads' flops) as three fp16 MFMA products of hi / lo operand planes staged once (mk_conv3x3_split)."""
     return str(cfg["AMD"].get("HEADS_DTYPE", "auto")).lower() == "split"
 
 
@@ -259,21 +259,16 @@ class MickeyRelativePose(nn.Module):
         im0, im1 = (t if t.stride(3) == 1 else t.contiguous() for t in (im0, im1))   # the patch kernel takes any outer strides
         imgs = [(im0, im1)] if same else [(im0,), (im1,)]
         outs = []
-        if self.heads_split:
+        if self.heads_split and self._sat_flag is None:
             # split-operand heads hold activations as x * 64 = hi + lo in fp16: a value beyond +-1023 is clamped.  The kernels
-            # report it into this word (split_saturated() reads it): never silently
-            from . import ops
-            if self._sat_flag is None:
-                self._sat_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
-            ops.split_watch_saturation(self._sat_flag)
-        try:
-            for im in imgs:
-                feat, gh, gw = pipeline.encoder_forward(W, self._ws, im)
-                scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, sum(t.shape[0] for t in im), gh, gw, self.cfg)
-                outs.append((scr, kps, depth, dsc, gh, gw))
-        finally:
-            if self.heads_split:
-                ops.split_watch_saturation(None)
+            # report it (and any NaN) into this word, passed to every plane-writing call through the model's own workspace --
+            # per model, never process-wide (split_saturated() reads it): never silently
+            self._sat_flag = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self._ws.sat_flag = self._sat_flag if self.heads_split else None
+        for im in imgs:
+            feat, gh, gw = pipeline.encoder_forward(W, self._ws, im)
+            scr, kps, depth, dsc = pipeline.heads_forward(W, self._ws, feat, sum(t.shape[0] for t in im), gh, gw, self.cfg)
+            outs.append((scr, kps, depth, dsc, gh, gw))
         if same:
             scr, kps, depth, dsc, gh, gw = outs[0]
             parts = [(scr[:B], kps[:B], depth[:B], dsc[:B], gh, gw), (scr[B:], kps[B:], depth[B:], dsc[B:], gh, gw)]

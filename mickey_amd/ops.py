@@ -137,9 +137,10 @@ def cls_token(cls, pos, x, nimg, ntok, D):
 
 
 def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows_out=None, rows_per_img=None, skip=0,
-              ldo=None, wgroup_rows=0, ldx=None, ldr=None, bordered=None):
+              ldo=None, wgroup_rows=0, ldx=None, ldr=None, bordered=None, sat=None):
     """LayerNorm rows of fp32 x [rows, D]; see mk_layernorm for the row remap and the residual form.
-    bordered = (nimg, H, W): `out` is a stack of bordered feature maps (rows_out = k * nimg * H * W pixels)."""
+    bordered = (nimg, H, W): `out` is a stack of bordered feature maps (rows_out = k * nimg * H * W pixels).
+    sat (plane outputs only): the saturation word (sat_word)."""
     D = w.shape[-1]
     rows_in = x.numel() // x.shape[-1]
     if rows_per_img is None:
@@ -153,7 +154,7 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
         bh, bw, bm = (bordered[1], bordered[2], bordered[0] * bordered[1] * bordered[2]) if bordered else (0, 0, 0)
         call("mk_layernorm_planes", ptr(x), x.stride(-2) if ldx is None else ldx, ptr(w), ptr(b), float(eps), ptr(oh), ptr(ol), ldo,
              SPLIT_ACT_SCALE, ptr(resid), (resid.stride(-2) if resid is not None else D) if ldr is None else ldr, rows_out, D,
-             rows_per_img, skip, wgroup_rows, bh, bw, bm, stream())
+             rows_per_img, skip, wgroup_rows, bh, bw, bm, sat_word(sat), stream())
         return out
     if out is None and out_dtype is not None:
         out = torch.empty((rows_out, D), device=x.device, dtype=out_dtype)
@@ -211,10 +212,27 @@ def conv3x3(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=N
 SPLIT_ACT_SCALE, SPLIT_W_SCALE = 64.0, 1024.0   # powers of two: activations up to 1023, weights up to 63 stay finite in fp16
 
 
-def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
+def sat_word(flag):
+    """The per-call saturation word of the plane-writing entry points (mickey_hip.h: sat_flag): None, or a zero-initialised
+    int32 [1] device tensor that a kernel ORs 1 into when it had to clamp |x * scale| at fp16's largest finite value or met a
+    NaN.  Returns the device pointer (None = nobody watches: no per-element work)."""
+    if flag is None:
+        return None
+    assert flag.dtype == torch.int32 and flag.numel() >= 1 and flag.is_cuda
+    return ptr(flag)
+
+
+def plane_pair(shape, device, zero=False):
+    """(hi, lo) fp16 planes as the two halves of ONE allocation: the split-operand kernels address both planes of a source from
+    one base pointer (mickey_hip.h: within 2 GiB of each other)."""
+    t = (torch.zeros if zero else torch.empty)((2,) + tuple(shape), device=device, dtype=torch.float16)
+    return t[0], t[1]
+
+
+def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE, sat=None):
     """fp32 tensor -> fp16 planes with x * scale = hi + lo (mk_split_planes); hi / lo: preallocated, same shape.  x, hi, lo
     may be column blocks of wider row-major matrices (views whose last dimension is contiguous and whose rows are
-    equidistant, e.g. t[..., :C])."""
+    equidistant, e.g. t[..., :C]).  sat: the saturation word (sat_word)."""
     assert x.dtype == torch.float32 and hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == x.shape == lo.shape
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -226,29 +244,31 @@ def split_planes(x, hi, lo, scale=SPLIT_ACT_SCALE):
             assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "rows must be equidistant"
         return lead
     assert ld(hi) == ld(lo)
-    call("mk_split_planes", ptr(x), rows, cols, ld(x), float(scale), ptr(hi), ptr(lo), ld(hi), stream())
+    call("mk_split_planes", ptr(x), rows, cols, ld(x), float(scale), ptr(hi), ptr(lo), ld(hi), sat_word(sat), stream())
     return hi, lo
 
 
 def gemm_grouped_split(a, w, bias, out, groups, M, N, K, lda, ldc, stride_a, stride_w, stride_bias, stride_out, act=ACT_NONE,
-                       w_scale=SPLIT_W_SCALE):
-    """mk_gemm_grouped_split: a = (hi, lo) fp16 planes [groups, M, lda], w fp16 [groups, N, 3 K]; out fp32 or a (hi, lo) pair."""
+                       w_scale=SPLIT_W_SCALE, sat=None):
+    """mk_gemm_grouped_split: a = (hi, lo) fp16 planes [groups, M, lda] (one allocation: plane_pair), w fp16 [groups, N, 2 K]
+    (weights.split_conv_weight); out fp32 or a (hi, lo) pair."""
     ah, al = a
-    assert w.dtype == torch.float16 and w.shape[-1] == 3 * K
+    assert w.dtype == torch.float16 and w.shape[-1] == 2 * K
     if isinstance(out, (tuple, list)):
         oh, ol = out
     else:
         oh, ol = out, None
         assert out.dtype == torch.float32
-    call("mk_gemm_grouped_split", ptr(ah), ptr(al), lda, stride_a, ptr(w), 3 * K, stride_w, ptr(bias), stride_bias, ptr(oh), ptr(ol),
-         ldc, stride_out, groups, M, N, K, act, 1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, stream())
+    call("mk_gemm_grouped_split", ptr(ah), ptr(al), lda, stride_a, ptr(w), 2 * K, stride_w, ptr(bias), stride_bias, ptr(oh), ptr(ol),
+         ldc, stride_out, groups, M, N, K, act, 1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, sat_word(sat), stream())
     return out
 
 
 def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE, in2=None, C2=0, stride_in1=0, stride_in2=0,
-                  stride_w=0, stride_bias=0, stride_out=0, out_bordered=False, w_scale=SPLIT_W_SCALE):
-    """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes, w fp16 [.., Cout, 3 K]; out: an fp32 tensor, or
-    a (hi, lo) pair of fp16 planes = the operand form of the next split conv (no fp32 round trip, no mk_split_planes pass)."""
+                  stride_w=0, stride_bias=0, stride_out=0, out_bordered=False, w_scale=SPLIT_W_SCALE, sat=None):
+    """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes (each pair one allocation: plane_pair), w fp16
+    [.., Cout, 2 K] (weights.split_conv_weight); out: an fp32 tensor, or a (hi, lo) pair of fp16 planes = the operand form of
+    the next split conv (no fp32 round trip, no mk_split_planes pass)."""
     assert w.dtype == torch.float16
     h1, l1 = in1
     h2, l2 = in2 if in2 is not None else (None, None)
@@ -260,7 +280,7 @@ def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE,
         assert out.dtype == torch.float32
     call("mk_conv3x3_split", ptr(h1), ptr(l1), stride_in1, C1, ptr(h2), ptr(l2), stride_in2, C2, ptr(w), w.shape[-1], stride_w,
          ptr(bias), stride_bias, ptr(oh), ptr(ol), Cout, stride_out, groups, nimg, H, W, act, int(out_bordered),
-         1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, stream())
+         1.0 / (SPLIT_ACT_SCALE * float(w_scale)), SPLIT_ACT_SCALE, sat_word(sat), stream())
     return out
 
 
@@ -365,15 +385,6 @@ def mutual_nn(scores):
 def counter_add(counter, inc):
     """counter (int64 CUDA tensor, 1 element) += inc on the current stream (see mk_counter_add)."""
     call("mk_counter_add", ptr(counter), int(inc), stream())
-
-
-def split_watch_saturation(flag):
-    """Dev / diagnostic (mickey_hip_dev.h): `flag` = a zero-initialised int32 [1] device tensor that every plane-writing kernel of
-    the split-operand head pipeline ORs 1 into when it had to clamp |x * scale| at fp16's largest finite value; None = stop
-    watching (the default).  Process-wide."""
-    if flag is not None:
-        assert flag.dtype == torch.int32 and flag.numel() >= 1 and flag.is_cuda
-    call("mk_split_watch_saturation", ptr(flag))
 
 
 def exprace_set_mode(mode):

@@ -17,6 +17,13 @@ class Workspace:
 
     def __init__(self):
         self.bufs = {}
+        self.sat_flag = None   # split-operand heads: the int32 [1] device word the plane-writing kernels report saturation into
+
+    def get_planes(self, name, shape, device, zero=False):
+        """(hi, lo) fp16 planes of a split-operand activation: the two halves of ONE buffer (the kernels address both planes of
+        a source from one base pointer, mickey_hip.h)."""
+        t = self.get(name, (2,) + tuple(shape), torch.float16, device, zero=zero)
+        return t[0], t[1]
 
     def get(self, name, shape, dtype, device, zero=False):
         key = (name, tuple(shape), dtype)
@@ -94,12 +101,11 @@ def encoder_forward(W, ws, img):
     R = ops.bordered_rows(nimg, gh, gw)
     if getattr(W, "heads_split", False):
         # split-operand heads: the final norm writes the convs' (hi, lo) fp16 operand planes directly (no fp32 feature map)
-        feat = (ws.get("feat_hi_%d_%d_%d" % (nimg, gh, gw), (R, D), torch.float16, dev, zero=True),
-                ws.get("feat_lo_%d_%d_%d" % (nimg, gh, gw), (R, D), torch.float16, dev, zero=True))
+        feat = ws.get_planes("feat_hl_%d_%d_%d" % (nimg, gh, gw), (R, D), dev, zero=True)
     else:
         feat = ws.get("feat_%d_%d_%d" % (nimg, gh, gw), (R, D), getattr(W, "lp_heads", lp), dev, zero=True)
     ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
-                  bordered=(nimg, gh, gw))
+                  bordered=(nimg, gh, gw), sat=ws.sat_flag)
     return feat, gh, gw
 
 
@@ -116,6 +122,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     R = ops.bordered_rows(nimg, gh, gw)
     geo = "_%d_%d_%d" % (nimg, gh, gw)   # bordered buffers: the workspace key carries the geometry (see encoder_forward)
     split = bool(getattr(W, "heads_split", False))   # 3x3 convs on split fp16 operands inside the fp32 head pipeline
+    sat = ws.sat_flag   # the plane-writing kernels report saturation / NaN here (per workspace = per model: no shared word)
 
     def wsc(w):   # power-of-two scale of a split weight tensor's planes (set by weights.prepare on the tensor object)
         sc = getattr(w, "mk_scale", None)
@@ -126,7 +133,7 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
 
     def plane_pair(name, shape):
         """Zeroed (hi, lo) fp16 planes of a bordered activation that a split conv WRITES (the next split conv's operands)."""
-        return (ws.get(name + "_hi" + geo, shape, torch.float16, dev, zero=True), ws.get(name + "_lo" + geo, shape, torch.float16, dev, zero=True))
+        return ws.get_planes(name + "_hl" + geo, shape, dev, zero=True)
 
     x_in, c_in, s_in = feat, W.D, 0   # first block: all four heads read the same feature map
     xp = feat if split else None   # (the final norm wrote the planes)
@@ -137,10 +144,10 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
             # conv -> conv inside the stack: the epilogue writes the next conv's (hi, lo) operand planes directly (no fp32
             # round trip, no mk_split_planes pass); only the stack's output (read by the row-wise attention kernels) is fp32
             hp = plane_pair("rb%d_h" % bi, (G, R, co))
-            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in, w_scale=wsc(rb.w1),
+            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in, w_scale=wsc(rb.w1), sat=sat,
                               stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
             xo = ws.get("rb%d_x" % bi + geo, (G, M, co), lp, dev) if last else plane_pair("rb%d_x" % bi, (G, R, co))
-            ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in, w_scale=wsc(rb.w2),
+            ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in, w_scale=wsc(rb.w2), sat=sat,
                               stride_in1=R * co, stride_in2=s_in, stride_w=rb.w2.shape[1] * rb.w2.shape[2], stride_bias=co,
                               stride_out=(M if last else R) * co, out_bordered=not last)
             if not last:
@@ -181,26 +188,26 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
         # the layers' small linears on split operands too (fp32 MFMA: 4.9 ms per 32 pairs; split: the conversions below + 12
         # HBM-bound GEMMs): planes of `cat` (its two column halves are rewritten at different times), of `msg`, and `hid`
         # written as planes by the GEMM that produces it
-        catp = (ws.get("att_cat_hi", (G, M, 2 * C), torch.float16, dev), ws.get("att_cat_lo", (G, M, 2 * C), torch.float16, dev))
-        msgp = (ws.get("att_msg_hi", (G, M, C), torch.float16, dev), ws.get("att_msg_lo", (G, M, C), torch.float16, dev))
-        hidp = (ws.get("att_hid_hi", (G, M, 2 * C), torch.float16, dev), ws.get("att_hid_lo", (G, M, 2 * C), torch.float16, dev))
+        catp = ws.get_planes("att_cat_hl", (G, M, 2 * C), dev)
+        msgp = ws.get_planes("att_msg_hl", (G, M, C), dev)
+        hidp = ws.get_planes("att_hid_hl", (G, M, 2 * C), dev)
     for li, lay in enumerate(W.att):
         last = li == nl - 1
         if split:
             if li == 0:   # later layers: the previous layer's closing LayerNorm wrote these planes
-                ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C])
-            ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 3 * C, 0, M * 3 * C,
-                                   w_scale=wsc(lay.qkv_w))
+                ops.split_planes(cat[:, :, :C], catp[0][:, :, :C], catp[1][:, :, :C], sat=sat)
+            ops.gemm_grouped_split(catp, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, 3 * C, M * 2 * C, 3 * C * 2 * C, 0, M * 3 * C,
+                                   w_scale=wsc(lay.qkv_w), sat=sat)
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
             ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
-            ops.split_planes(msg, msgp[0], msgp[1])
-            ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 3 * C, 0, M * C, w_scale=wsc(lay.merge_w))
+            ops.split_planes(msg, msgp[0], msgp[1], sat=sat)
+            ops.gemm_grouped_split(msgp, lay.merge_w, None, mrg, G, M, C, C, C, C, M * C, C * 2 * C, 0, M * C, w_scale=wsc(lay.merge_w), sat=sat)
             ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=(catp[0][:, :, C:], catp[1][:, :, C:]), ldo=2 * C, rows_out=G * M,
-                          rows_per_img=G * M, wgroup_rows=M)
-            ops.gemm_grouped_split(catp, lay.mlp0_w, None, hidp, G, M, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 2 * C * 3 * 2 * C, 0,
-                                   M * 2 * C, act=ops.ACT_RELU, w_scale=wsc(lay.mlp0_w))
-            ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 3 * 2 * C, 0, M * C,
-                                   w_scale=wsc(lay.mlp2_w))
+                          rows_per_img=G * M, wgroup_rows=M, sat=sat)
+            ops.gemm_grouped_split(catp, lay.mlp0_w, None, hidp, G, M, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 2 * C * 2 * 2 * C, 0,
+                                   M * 2 * C, act=ops.ACT_RELU, w_scale=wsc(lay.mlp0_w), sat=sat)
+            ops.gemm_grouped_split(hidp, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, C, M * 2 * C, C * 2 * 2 * C, 0, M * C,
+                                   w_scale=wsc(lay.mlp2_w), sat=sat)
         else:
             ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
@@ -216,7 +223,8 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
         else:
             o2 = x4 if last else cat
         ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=o2, ldo=C if last else 2 * C, resid=xs,
-                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None)
+                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None,
+                      sat=sat if split else None)
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout
@@ -225,14 +233,14 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
     fd = ws.get("rb4_fd", (M, cd), torch.float32, dev)
     if split:
         h4p = plane_pair("rb4_h", (3, R, ck))
-        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C, w_scale=wsc(kpw.w1),
+        ops.conv3x3_split((x4h[:3], x4l[:3]), C, kpw.w1, kpw.b1, h4p, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=R * C, w_scale=wsc(kpw.w1), sat=sat,
                           stride_w=kpw.w1.shape[1] * kpw.w1.shape[2], stride_bias=ck, stride_out=R * ck, out_bordered=True)
         assert kpw.has_sc and dw.has_sc   # (weights.prepare gives the descriptor block identity shortcut columns in this mode)
         ops.conv3x3_split(h4p, ck, kpw.w2, kpw.b2, f4, ck, 3, nimg, gh, gw, act=ops.ACT_RELU, w_scale=wsc(kpw.w2),
                           in2=(x4h[:3], x4l[:3]), C2=C, stride_in1=R * ck, stride_in2=R * C,
                           stride_w=kpw.w2.shape[1] * kpw.w2.shape[2], stride_bias=ck, stride_out=M * ck)
         hdp = plane_pair("rb4_hd", (R, cd))
-        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hdp, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True, w_scale=wsc(dw.w1))
+        ops.conv3x3_split((x4h[3], x4l[3]), C, dw.w1, dw.b1, hdp, cd, 1, nimg, gh, gw, act=ops.ACT_RELU, out_bordered=True, w_scale=wsc(dw.w1), sat=sat)
         ops.conv3x3_split(hdp, cd, dw.w2, dw.b2, fd, cd, 1, nimg, gh, gw, act=ops.ACT_NONE, w_scale=wsc(dw.w2),
                           in2=(x4h[3], x4l[3]), C2=C)   # relu=False, mickey_extractor.py:246
     else:

@@ -116,23 +116,37 @@ def split_weight_scale(w, target=1024.0):
 
 
 def split_conv_weight(w, scale=None):
-    """[.., Cout, K] fp32 (BatchNorm folded) -> fp16 [.., Cout, 3 K] = [W_hi | W_lo | W_hi] of w * scale, w * scale = hi + lo:
-    the K layout mk_conv3x3_split sweeps (sweep 0 pairs the LO activation planes with W_hi, 1: hi x lo, 2: hi x hi).
+    """[.., Cout, K] fp32 (BatchNorm folded) -> fp16 [.., Cout, 2 K]: the (hi, lo) planes of w * scale (w * scale = hi + lo)
+    INTERLEAVED per block of 32 K columns -- 32 hi values, then the 32 lo values of the same columns: one 128-byte LDS row of
+    a K step of mk_conv3x3_split / mk_gemm_grouped_split (mickey_hip.h: the four planes a_hi, a_lo, w_hi, w_lo are staged once
+    per K step and the products hi.hi + lo.hi + hi.lo are issued from those fragments).  K % 32 == 0.
     scale: a power of two, default split_weight_scale(w); the caller passes the same value as `w_scale` to the kernel wrapper."""
     scale = split_weight_scale(w) if scale is None else scale
+    K = w.shape[-1]
+    assert K % 32 == 0, "split-operand weights: K must be a multiple of 32"
     ws = w.float() * scale
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
-    out = torch.cat([hi, lo, hi], -1)
+    lead = tuple(w.shape[:-1])
+    out = torch.stack([hi.reshape(lead + (K // 32, 32)), lo.reshape(lead + (K // 32, 32))], -2).reshape(lead + (2 * K,))
     assert bool(torch.isfinite(out).all()), "weights do not fit fp16 planes"
     return out
+
+
+def split_conv_weight_planes(planes):
+    """Inverse view of split_conv_weight: [.., 2 K] interleaved -> (hi [.., K], lo [.., K]) (tests, diagnostics)."""
+    K2 = planes.shape[-1]
+    v = planes.reshape(tuple(planes.shape[:-1]) + (K2 // 64, 2, 32))
+    lead = tuple(planes.shape[:-1])
+    return v[..., 0, :].reshape(lead + (K2 // 2,)), v[..., 1, :].reshape(lead + (K2 // 2,))
 
 
 def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True, heads_split=False):
     """heads_dtype: operand type of the four head stacks (None = lp_dtype; torch.float32 = as the reference, which always
     runs them in fp32, mickey_extractor.py:53-56) while the encoder uses lp_dtype.  heads_split (with heads_dtype fp32): the
     3x3 convolutions -- 99 % of the heads' flops -- run on the 16-bit matrix cores with split fp16 operands
-    (mk_conv3x3_split: fp32-grade products, three MFMA passes), everything else of the heads stays on the fp32 path."""
+    (mk_conv3x3_split: fp32-grade products, three MFMA sets on operands staged once), everything else of the heads stays on the
+    fp32 path."""
     W = prepare_encoder(sd, device, lp_dtype, ln_fold=ln_fold, ln_centre=ln_centre)
     dev = device
     W.lp_heads = lp_dtype if heads_dtype is None else heads_dtype
@@ -190,7 +204,7 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
         lay = DeviceWeights()
         def stk(name):
             return torch.stack([sd[e + h + ".att_layer.layers.%d.%s" % (l, name)].float() for h in HEADS])
-        # (split mode: the same [W_hi | W_lo | W_hi] K layout as the convs, for mk_gemm_grouped_split)
+        # (split mode: the same interleaved (hi | lo) K layout as the convs, for mk_gemm_grouped_split)
         lay.qkv_w = convw(torch.cat([stk("q_proj.weight"), stk("k_proj.weight"), stk("v_proj.weight")], 1))  # [4,384,128]
         lay.merge_w = convw(stk("merge.weight"))
         lay.mlp0_w, lay.mlp2_w = convw(stk("mlp.0.weight")), convw(stk("mlp.2.weight"))

@@ -297,8 +297,8 @@ def test_bordered_index_matches_the_library():
 
 def test_split_operand_scheme_is_fp32_grade():
     """The arithmetic behind mk_conv3x3_split / mk_gemm_grouped_split / mk_dual_softmax_split, emulated on the CPU with the
-    host-side preparation the product uses (weights.split_conv_weight): x * 64 and w * scale as hi + lo fp16 planes, three
-    sweeps lo.hi + hi.lo + hi.hi with fp32-or-better accumulation, scaled back by 1 / (64 scale).  The dropped lo.lo term and
+    host-side preparation the product uses (weights.split_conv_weight): x * 64 and w * scale as hi + lo fp16 planes, the three
+    products hi.hi + lo.hi + hi.lo with fp32-or-better accumulation, scaled back by 1 / (64 scale).  The dropped lo.lo term and
     the planes' rounding leave ~22 bits: <= 2e-6 relative against the exact fp64 product -- also for weights so large
     (BatchNorm folded over a tiny variance) that the plane scale has to come down, and for activations near the planes' range."""
     import torch
@@ -310,9 +310,11 @@ def test_split_operand_scheme_is_fp32_grade():
         x = torch.randn((M, K), generator=g) * xmag
         sw = weights.split_weight_scale(w)
         assert sw == 2.0 ** round(math.log2(sw)) and float(w.abs().max()) * sw <= 32768.0
-        planes = weights.split_conv_weight(w, sw)                 # [Cout, 3K] = [W_hi | W_lo | W_hi]
-        w_hi, w_lo = planes[:, :K].double(), planes[:, K:2 * K].double()
-        assert torch.equal(planes[:, 2 * K:], planes[:, :K])
+        planes = weights.split_conv_weight(w, sw)                 # [Cout, 2K]: per 32 columns, 32 hi then 32 lo values
+        assert planes.shape == (Cout, 2 * K) and planes.dtype == torch.float16
+        w_hi, w_lo = (t.double() for t in weights.split_conv_weight_planes(planes))
+        assert torch.equal(planes[:, 64:96], w_hi[:, 32:64].half()) and torch.equal(planes[:, 96:128], w_lo[:, 32:64].half())
+        assert torch.equal(w_hi.float(), (w * sw).half().float())
         xs = x * ops.SPLIT_ACT_SCALE
         x_hi = xs.clamp(-65504.0, 65504.0).to(torch.float16)
         x_lo = (xs - x_hi.float()).to(torch.float16)

@@ -620,37 +620,68 @@ def test_flash_attention_queries_per_wave_bit_identical(pair):
 
 
 def test_split_planes_saturation_is_reported():
-    """x * 64 = hi + lo in fp16 saturates at |x| > 1023.  With a watcher word registered (mk_split_watch_saturation) every
-    plane-writing kernel reports a clamp; in range nothing is reported; without a watcher nothing is touched."""
+    """x * 64 = hi + lo in fp16 saturates at |x| > 1023.  With a watcher word passed to the call (mickey_hip.h: sat_flag) every
+    plane-writing kernel reports a clamp; in range nothing is reported; without a word nothing is touched.  A NaN is reported
+    AND stays a NaN in both planes (it must reach the outputs' finite checks, not turn into -65504)."""
     from mickey_amd import ops
     dev = _dev()
     flag = torch.zeros((1,), device=dev, dtype=torch.int32)
     x = torch.randn((64, 256), generator=g(3)).to(dev) * 100.0          # |x| < 1023
-    hi, lo = torch.empty_like(x, dtype=torch.float16), torch.empty_like(x, dtype=torch.float16)
+    hi, lo = ops.plane_pair(x.shape, dev)
     w, b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
-    try:
-        ops.split_watch_saturation(flag)
-        ops.split_planes(x, hi, lo)
-        assert int(flag.item()) == 0
-        assert rel((hi.float() + lo.float()) / 64.0, x) < 1e-6
-        x2 = x.clone()
-        x2[5, 7] = 2000.0                                                # beyond the planes' range
-        ops.split_planes(x2, hi, lo)
-        assert int(flag.item()) == 1 and float(hi[5, 7]) == 65504.0
-        flag.zero_()
-        x3 = x.clone()
-        x3[9, 1] = float("nan")
-        ops.split_planes(x3, hi, lo)
-        assert int(flag.item()) == 1                                     # NaN is a clamp too (fminf / fmaxf drop it)
-        flag.zero_()
-        ops.layernorm(x * 0.01, w * 3000.0, b, 1e-6, out=(hi, lo))       # LayerNorm output (unit variance) x 3000: out of range
-        assert int(flag.item()) == 1
-        flag.zero_()
-        ops.split_watch_saturation(None)
-        ops.split_planes(x2, hi, lo)
-        assert int(flag.item()) == 0                                     # nobody watches: the word is left alone
-    finally:
-        ops.split_watch_saturation(None)
+    ops.split_planes(x, hi, lo, sat=flag)
+    assert int(flag.item()) == 0
+    assert rel((hi.float() + lo.float()) / 64.0, x) < 1e-6
+    x2 = x.clone()
+    x2[5, 7] = 2000.0                                                # beyond the planes' range
+    x2[6, 8] = -5000.0
+    ops.split_planes(x2, hi, lo, sat=flag)
+    assert int(flag.item()) == 1 and float(hi[5, 7]) == 65504.0 and float(hi[6, 8]) == -65504.0
+    flag.zero_()
+    x3 = x.clone()
+    x3[9, 1] = float("nan")
+    ops.split_planes(x3, hi, lo, sat=flag)
+    assert int(flag.item()) == 1                                     # NaN is reported ...
+    assert bool(torch.isnan(hi[9, 1])) and bool(torch.isnan(lo[9, 1]))   # ... and propagated
+    assert int(torch.isnan(hi).sum()) == 1
+    flag.zero_()
+    ops.layernorm(x * 0.01, w * 3000.0, b, 1e-6, out=(hi, lo), sat=flag)   # LayerNorm output (unit variance) x 3000: out of range
+    assert int(flag.item()) == 1
+    flag.zero_()
+    ops.split_planes(x2, hi, lo)
+    assert int(flag.item()) == 0                                     # nobody watches: the word is left alone
+
+
+def test_saturation_words_of_two_streams_are_independent():
+    """The saturation word is a per-call argument (no process-wide watcher): two plane-writing pipelines interleaved on two
+    streams, one fed out-of-range values and one in range, report into their own words only -- split_planes, the LayerNorm
+    that writes planes, and the plane-writing epilogues of the split conv / split grouped GEMM."""
+    from mickey_amd import ops, weights
+    dev = _dev()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    fa = torch.zeros((1,), device=dev, dtype=torch.int32)
+    fb = torch.zeros((1,), device=dev, dtype=torch.int32)
+    G, M, N, K = 2, 3000, 128, 128
+    a_ok = torch.randn((G, M, K), generator=g(1)).to(dev)
+    a_big = a_ok * 40.0                                   # products of ~ +-40 * sqrt(K): the OUTPUT planes (x 64) overflow
+    w = torch.randn((G, N, K), generator=g(2))
+    ws = weights.split_conv_weight(w).to(dev).contiguous()
+    lnw, lnb = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+    torch.cuda.synchronize()
+    outs = {}
+    for it in range(3):
+        for name, st, flag, src in (("a", sa, fa, a_big), ("b", sb, fb, a_ok)):
+            with torch.cuda.stream(st):
+                ah, al = ops.plane_pair(src.shape, dev)
+                ops.split_planes(src, ah, al, sat=flag)
+                oh, ol = ops.plane_pair((G, M, N), dev)
+                ops.gemm_grouped_split((ah, al), ws, None, (oh, ol), G, M, N, K, K, N, M * K, N * 2 * K, 0, M * N, sat=flag)
+                lh, ll = ops.plane_pair((G * M, K), dev)
+                ops.layernorm(src.reshape(G * M, K), lnw * (2000.0 if name == "a" else 1.0), lnb, 1e-6, out=(lh, ll), sat=flag)
+                outs[name] = (oh, ol)
+    torch.cuda.synchronize()
+    assert int(fa.item()) == 1 and int(fb.item()) == 0
+    assert bool(torch.isfinite(outs["b"][0]).all())
 
 
 def _to_bordered(x, nimg, H, W):
@@ -747,10 +778,12 @@ def test_conv3x3_big_tiles_and_tiny_grids(nimg, H, W):
 
 @pytest.mark.parametrize("nimg,H,W,G,C1,C2,Cout,bordered", [(2, 9, 7, 3, 128, 64, 192, True),     # 128x128 tiles, shortcut source
                                                             (2, 9, 7, 2, 64, 0, 64, False),       # no second source, dense rows
+                                                            (2, 9, 7, 2, 96, 32, 64, True),       # channel counts of 32-granularity
                                                             (32, 51, 38, 1, 64, 64, 256, True),   # 256x256 ping-pong tiles
+                                                            (32, 51, 38, 1, 96, 32, 256, False),  # ... at 32-granularity (odd stage counts)
                                                             (32, 51, 38, 2, 64, 0, 320, False)])
 def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
-    """mk_conv3x3_split: fp32 activations / weights as fp16 hi + lo planes, three MFMA sweeps -- against an fp64 evaluation of
+    """mk_conv3x3_split: fp32 activations / weights as fp16 hi + lo planes staged once, three MFMA products -- against an fp64 evaluation of
     the SAME fp32 values its error must be that of an fp32 evaluation (beside it), far below one fp16 rounding (2^-11 =
     4.9e-4).  Activations carry a wide range of magnitudes (the lo plane's subnormal end) and exact zeros (post-ReLU); both
     kernels (128x128 and the 256x256 ping-pong), shared / per-group sources, dense and bordered fp32 output.  The references
@@ -770,19 +803,19 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
         w2d = torch.cat([w2d, wsc], 2)
     K = w2d.shape[2]
     wsplit = weights.split_conv_weight(w2d).to(dev).contiguous()
-    assert wsplit.shape == (G, Cout, 3 * K) and wsplit.dtype == torch.float16
+    assert wsplit.shape == (G, Cout, 2 * K) and wsplit.dtype == torch.float16
     R = ops.bordered_rows(nimg, H, W)
     xb = _to_bordered(x, nimg, H, W)                         # fp32 [G, R, C1]
-    xh, xl = ops.split_planes(xb, torch.empty_like(xb, dtype=torch.float16), torch.empty_like(xb, dtype=torch.float16))
+    xh, xl = ops.split_planes(xb, *ops.plane_pair(xb.shape, dev))
     resid = (xh.double() + xl.double() - xb.double() * ops.SPLIT_ACT_SCALE).abs().max()
     assert float(resid) <= 2.0 ** -21 * float(xb.max()) * ops.SPLIT_ACT_SCALE + 1e-7, float(resid)
     in2 = None
     if C2:
         x2b = _to_bordered(x2, nimg, H, W)
-        in2 = ops.split_planes(x2b, torch.empty_like(x2b, dtype=torch.float16), torch.empty_like(x2b, dtype=torch.float16))
+        in2 = ops.split_planes(x2b, *ops.plane_pair(x2b.shape, dev))
     out = torch.full((G, R if bordered else M, Cout), 7.0, device=dev, dtype=torch.float32)
     ops.conv3x3_split((xh, xl), C1, wsplit, bias, out, Cout, G, nimg, H, W, act=ops.ACT_RELU, in2=in2, C2=C2,
-                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 3 * K, stride_bias=Cout, stride_out=out.shape[1] * Cout,
+                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 2 * K, stride_bias=Cout, stride_out=out.shape[1] * Cout,
                       out_bordered=bordered)
     if bordered:
         idx = ops.bordered_index(nimg, H, W, dev)
@@ -809,7 +842,7 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
     ph = torch.full((G, rows, Cout), 7.0, device=dev, dtype=torch.float16)
     pl = torch.full((G, rows, Cout), 7.0, device=dev, dtype=torch.float16)
     ops.conv3x3_split((xh, xl), C1, wsplit, bias, (ph, pl), Cout, G, nimg, H, W, act=ops.ACT_RELU, in2=in2, C2=C2,
-                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 3 * K, stride_bias=Cout, stride_out=rows * Cout,
+                      stride_in1=R * C1, stride_in2=0, stride_w=Cout * 2 * K, stride_bias=Cout, stride_out=rows * Cout,
                       out_bordered=bordered)
     if bordered:
         assert bool((ph[:, mask] == 7.0).all()) and bool((pl[:, mask] == 7.0).all())
@@ -818,11 +851,12 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
     assert float((back - out.double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
 
 
-@pytest.mark.parametrize("M,N,K,lda", [(500, 128, 128, 256), (40000, 384, 128, 256), (40000, 256, 256, 256), (3000, 128, 256, 256)])
+@pytest.mark.parametrize("M,N,K,lda", [(500, 128, 128, 256), (40000, 384, 128, 256), (40000, 256, 256, 256), (3000, 128, 256, 256),
+                                       (40000, 256, 96, 256), (700, 64, 32, 64)])
 def test_grouped_gemm_split_is_fp32_grade(M, N, K, lda):
     """mk_gemm_grouped_split (the heads' small linears in AMD.HEADS_DTYPE: split): fp32 A [G, M, lda] as (hi, lo) planes -- also
     converted as two column blocks at different times, as the pipeline does with `cat` -- times fp32 weights in the
-    [W_hi | W_lo | W_hi] layout, both kernels (128x128; 256x256 ping-pong for the 40000-row cases), fp32 output and the
+    interleaved (32 hi | 32 lo) layout, both kernels (128x128; 256x256 ping-pong for the 40000-row cases), fp32 output and the
     plane-output form with ReLU; against fp64."""
     from mickey_amd import ops, weights
     dev = _dev()
@@ -831,20 +865,20 @@ def test_grouped_gemm_split_is_fp32_grade(M, N, K, lda):
     a = (torch.randn((G, M, lda), generator=g(1)) * torch.exp(torch.randn((G, M, 1), generator=g(2)))).to(dev)
     w = (torch.randn((G, N, K), generator=g(3)) / math.sqrt(K))
     ws = weights.split_conv_weight(w).to(dev).contiguous()
-    ah, al = torch.empty_like(a, dtype=torch.float16), torch.empty_like(a, dtype=torch.float16)
+    ah, al = ops.plane_pair(a.shape, dev)
     half = lda // 2
     ops.split_planes(a[:, :, :half], ah[:, :, :half], al[:, :, :half])
     ops.split_planes(a[:, :, half:], ah[:, :, half:], al[:, :, half:])
     assert float((ah.double() + al.double() - a.double() * ops.SPLIT_ACT_SCALE).abs().max()) <= 2.0 ** -21 * float(a.abs().max()) * 64 + 1e-7
     out = torch.empty((G, M, N), device=dev, dtype=torch.float32)
-    ops.gemm_grouped_split((ah, al), ws, None, out, G, M, N, K, lda, N, M * lda, N * 3 * K, 0, M * N)
+    ops.gemm_grouped_split((ah, al), ws, None, out, G, M, N, K, lda, N, M * lda, N * 2 * K, 0, M * N)
     ref64 = torch.einsum("gmk,gnk->gmn", a[:, :, :K].double(), w.to(dev).double())
     ref32 = torch.einsum("gmk,gnk->gmn", a[:, :, :K], w.to(dev))
     e, e32 = rel(out, ref64), rel(ref32, ref64)
     print("split grouped GEMM vs fp64 %.2e (torch fp32 %.2e)" % (e, e32))
     assert e < 2e-6 and e < 4 * e32 + 2e-7
     oh, ol = torch.empty((G, M, N), device=dev, dtype=torch.float16), torch.empty((G, M, N), device=dev, dtype=torch.float16)
-    ops.gemm_grouped_split((ah, al), ws, None, (oh, ol), G, M, N, K, lda, N, M * lda, N * 3 * K, 0, M * N, act=ops.ACT_RELU)
+    ops.gemm_grouped_split((ah, al), ws, None, (oh, ol), G, M, N, K, lda, N, M * lda, N * 2 * K, 0, M * N, act=ops.ACT_RELU)
     back = (oh.double() + ol.double()) / ops.SPLIT_ACT_SCALE
     assert float((back - F.relu(out).double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
 

@@ -1,14 +1,14 @@
 #!/bin/bash
 # One development call on the GPU box: `gpurun -- 'TAG=r05a bash tools/gpu_call.sh <step> ...'`; every step writes under
 # gpurun_out/${TAG}_*.  Steps: tests:<pytest args>, bench[:<bench args>], matcher, sampler, gemm, attn, lnfold
-export TAG=${TAG:-r05x}
+export TAG=${TAG:-r06x}
 mkdir -p gpurun_out
 for step in "$@"; do
   name=${step%%:*}
   arg=""
   [ "$name" != "$step" ] && arg=${step#*:}
   case $name in
-    tests)   timeout 1500 python -m pytest $arg -q -m gpu -x -rf 2>&1 | tail -25 | tee gpurun_out/${TAG}_pytest_$(echo "$arg" | md5sum | cut -c1-6).txt ;;
+    tests)   eval "timeout 1500 python -m pytest $arg -q -m gpu -x -rf" 2>&1 | tail -25 | tee gpurun_out/${TAG}_pytest_$(echo "$arg" | md5sum | cut -c1-6).txt ;;
     bench)   SECONDS=0; timeout 900 python bench.py $arg 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
              cp gpurun_out/bench_detail.json gpurun_out/${TAG}_bench_detail.json 2>/dev/null
              echo "bench wall ${SECONDS}s" | tee gpurun_out/${TAG}_bench.time; wc -c gpurun_out/${TAG}_bench_b32.json; cat gpurun_out/${TAG}_bench_b32.json; tail -12 gpurun_out/${TAG}_bench.err ;;
