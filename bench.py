@@ -257,16 +257,47 @@ def cpu_baseline(cfg, sd):
         return t
 
     warm = one(False)   # warm-up (thread pools, allocator, first-touch of the weights)
-    med = min([warm, one(True)], key=lambda r: r["total"])   # one timed run behind it (~7 s each on 32 cores: the whole leg stays
-    #                                                           inside 10-30 s of CPU work); the faster of the two counts
+    runs = sorted([one(True) for _ in range(3)], key=lambda r: r["total"])
+    med = runs[1]       # the MEDIAN of 3 runs behind one warm-up (~7 s each on 32 cores: ~28 s of CPU work)
+    # thread-count probe (opt-in, --cpu-threads-probe): the same oracle on a SMALL pair (182x196) at the thread count used above and
+    # at os.cpu_count().  Not in the default run: measured once on the 256-core GPU box (profiles/r06g_bench_detail.json), the
+    # 182x196 pair took 0.61 s on 32 threads and 250 s on 256 -- torch-CPU collapses when every core takes part in these ops
+    probe = {"measured_once": {"box_cores": 256, "sample": "1 pair 182x196, same oracle", "seconds_threads_32": 0.6115,
+                               "seconds_threads_256": 249.97, "source": "profiles/r06g_bench_detail.json"}}
+    if getattr(cpu_baseline, "threads_probe", False):
+        try:
+            ncpu = os.cpu_count() or 1
+            small = syn.synthetic_batch(B=1, H=182, W=196, seed=1234)
+
+            def small_forward():
+                d = {k: v.clone() for k, v in small.items()}
+                with torch.no_grad():
+                    t0 = time.perf_counter()
+                    d.update(O.compute_correspondences(sd, cfg, d))
+                    O.estimate_pose(d, cfg)
+                    return time.perf_counter() - t0
+            probe["sample"] = "1 pair 182x196, same oracle, 1 warm-up + 1 timed run per setting"
+            for name, nt in (("threads_%d" % cores, cores), ("threads_%d" % ncpu, ncpu)):
+                if ("seconds_" + name) in probe:
+                    continue
+                torch.set_num_threads(nt)
+                small_forward()
+                probe["seconds_" + name] = round(small_forward(), 4)
+            torch.set_num_threads(cores)
+        except Exception as e:   # the probe never costs the baseline itself
+            probe["error"] = "%s: %s" % (type(e).__name__, e)
     return {"value": 1.0 / med["total"], "unit": "pairs/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
             "kind_note": "the oracle restatement, not the reference module itself: /root/reference does not exist on the GPU box; "
-                         "threads capped at 32 because torch-CPU gets slower beyond that on these ops",
+                         "threads capped at 32 because torch-CPU collapses beyond that on these ops (threads_probe: a 182x196 pair 0.61 s on 32 "
+                         "threads, 250 s on all 256).  The only "
+                         "reference-side measurement is the survey's: the reference module itself, 0.055 pairs/s on the 8 cores "
+                         "of the build container (BASELINE.md section 2)",
             "pinned_by": "tests/test_oracle_golden.py (the oracle vs the reference's own outputs, tests/golden/*.npz, regenerated "
                          "from /root/reference by oracle/make_golden.py in test_committed_fixtures_reproduce_from_the_reference)",
-            "protocol": "1 warm-up + 1 timed run, the faster counts", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
+            "protocol": "1 warm-up + 3 timed runs, the median counts", "stage_seconds": {k: round(v, 4) for k, v in med.items()},
+            "runs_total_seconds": [round(r["total"], 4) for r in runs], "threads_probe": probe,
             "sample": "1 pair 540x720, full forward (ViT-L fp32 + heads + dual-softmax + 20x100 RANSAC), torch-CPU "
-                      "oracle, %.2f s per pair (1 warm-up + 1 timed run)" % med["total"]}
+                      "oracle, %.2f s per pair (median of 3 after 1 warm-up)" % med["total"]}
 
 
 def precision_report(make_model, syn, dev, args, oracle_out):
@@ -334,12 +365,15 @@ def parse_args(argv=None):
                          "16-bit encoder; the reference runs them in fp32)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads-probe", action="store_true", help="CPU leg: also time a small pair at os.cpu_count() threads "
+                                                                     "(minutes on a 256-core host)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--legs", default="ref_split",
                     help="comma-separated extra legs, each a full timed run written to the detail file: fp16, ref_split, "
                          "ref_split_fp32mfma, attn_mfma16, vit_small, config5; 'all'; 'none'.  Default: ref_split only (the "
                          "reference's literal precision split, reported in the line as value_ref_precision)")
-    ap.add_argument("--sustained", action="store_true", help="also run the headline configuration over 60 steps (detail file)")
+    ap.add_argument("--sustained", action="store_true", help="(default since round 6; kept for old command lines)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step run of the headline configuration ('sustained_60' of the line)")
     ap.add_argument("--precision", action="store_true",
                     help="also report every feature output's error vs the CPU oracle outputs of this run (detail file)")
     ap.add_argument("--lean", action="store_true", help="only the headline measurement: no legs, no single-pair / CPU legs "
@@ -363,6 +397,7 @@ def parse_args(argv=None):
                          "sharding, gather and timing logic of --gpus N can be exercised under gloo without a GPU; "
                          "the printed line is marked \"stub\": true and is not a measurement")
     args = ap.parse_args(argv)
+    args.sustained = not args.no_sustained
     if args.lean:
         args.no_single = args.no_cpu_baseline = True
         args.include_h2d = args.sustained = args.precision = False
@@ -776,6 +811,7 @@ def main(argv=None):
         tick("legs measured")
         if world == 1 and not args.no_cpu_baseline:
             try:
+                cpu_baseline.threads_probe = bool(args.cpu_threads_probe)
                 out["cpu_baseline"] = cpu_baseline(cfg, sd)
                 tick("cpu baseline measured")
             except Exception as e:   # the line must still be printed (the contract's required keys stay present)
@@ -821,8 +857,10 @@ def compact_line(out, detail_path=None):
     else:
         line["roofline"] = None
     cb = out.get("cpu_baseline")
-    line["cpu_baseline"] = ({k: r4(cb.get(k)) for k in ("value", "unit", "cores", "cores_available", "kind", "sample") if k in cb}
-                            if cb else None)
+    line["cpu_baseline"] = ({k: r4(cb.get(k)) for k in ("value", "unit", "cores", "cores_available", "kind", "sample", "stage_seconds")
+                             if k in cb} if cb else None)
+    if (out.get("sustained") or {}).get("value") is not None:
+        line["sustained_60"] = r4(out["sustained"]["value"])   # the headline configuration over 60 back-to-back steps (pairs/s)
     rs = (out.get("legs") or {}).get("ref_split") or {}
     if "value" in rs:
         line["value_ref_precision"] = r4(rs["value"])
@@ -839,7 +877,7 @@ def compact_line(out, detail_path=None):
     txt = json.dumps(line, separators=(",", ":"))
     # cannot happen with the keys above; if it ever does, optional keys go first and free-text fields are cut -- the line is
     # printed whatever happens (an oversized or missing line is an unmeasured round)
-    for k in ("ref_precision", "detail", "stages", "single_pair_ms", "per_rank_ms_per_step"):
+    for k in ("ref_precision", "detail", "stages", "single_pair_ms", "per_rank_ms_per_step", "sustained_60"):
         if len(txt) < LINE_LIMIT:
             break
         line.pop(k, None)

@@ -316,11 +316,18 @@ int mk_mutual_nn(const float* scores, int* matches, int* count, int* work, int B
  *   invalid int32 [1] or NULL: OR-ed with 1 when torch.multinomial would have raised (a NaN / inf /
  *          negative probability, or a row without any positive cell) -- the reference then returns
  *          the zero pose for the whole batch (probabilisticProcrustes.py:331-336)
- *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k, ncell), 16-byte aligned
+ *   work   bytes: mk_exprace_topk_work_bytes(B, rows_per_pair, k, ncell), 16-byte aligned.  Its first
+ *          mk_exprace_topk_state_bytes(B, rows_per_pair) bytes are SELF-CLEANING state (per-row candidate counts, per-pair
+ *          flags and histograms, arrival counters): they must be ZERO when a call starts and every call leaves them zero, so
+ *          the chain carries no zero-fill launch -- zero the buffer once when it is allocated and reuse it; a buffer must not
+ *          be shared by calls that may run concurrently (two streams).  The chain is four launches: histogram of p (+ the
+ *          threshold as its tail), the collect pass (+ the shortfall check as its tail), the exact fallback (idle unless a
+ *          pair came up short), the select kernel.
  *   pair_base  GLOBAL index of pair 0 of this call.  The Philox streams are keyed by (seed, offset, global pair index,
  *          draw, cell), so a batch may be split arbitrarily -- over calls or over the GPUs of a node -- without changing
  *          any pair's draws: pair i of a B = 32 call and the same pair alone with pair_base = i sample identically. */
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k, long long ncell);
+long long mk_exprace_topk_state_bytes(int B, int rows_per_pair);
 int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed, unsigned long long offset,
                     const unsigned long long* offset_dev, int* idx, int* cnt, int* invalid, void* work, int B, int rows_per_pair,
                     long long ncell, int k, int pair_base, mk_stream_t stream);

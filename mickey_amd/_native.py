@@ -55,6 +55,7 @@ SIGNATURES = {
     "mk_sinkhorn": ("i", "ppppfippppiiiip"),
     "mk_mutual_nn": ("i", "ppppiiip"),
     "mk_exprace_topk_work_bytes": ("l", "iiil"),
+    "mk_exprace_topk_state_bytes": ("l", "ii"),
     "mk_exprace_topk": ("i", "ppuupppppiiliip"),
     "mk_counter_add": ("i", "pup"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),

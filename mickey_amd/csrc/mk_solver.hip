@@ -74,14 +74,17 @@ constexpr int RG = 4;           // rows per group = draws per Philox call
 constexpr int CAND_MAX = 8192;  // candidates kept per row (expected ~k * 1.1)
 constexpr int CELL_BLOCKS = 128;
 
+// Workspace of mk_exprace_topk.  The words of `ncand | redo | phist | done1` are SELF-CLEANING state: they must be zero
+// when a call starts and every call leaves them zero (each is reset by its last reader), so that no zero-fill launch stands in
+// front of the chain -- mickey_hip.h: the caller zero-initialises the buffer once and never shares it between streams.
 struct TopkWork {
-  unsigned* hist;            // [R][NBINS]   key histogram of the exact (fallback) path
+  unsigned* ncand;           // [R]          (state) candidates appended per row; reset by the select kernel
+  int* redo;                 // [B]          (state) per pair: set when one of its rows collected fewer than k candidates above an
+                             //     analytic threshold or a workgroup's queue overflowed -- the exact fallback then redoes THAT pair only
+                             //     (the others keep their skip-sampler draws: a pair's result never depends on its batch)
+  unsigned* phist;           // [B][NBINS]   (state) histogram of p itself (analytic threshold); reset by its pair's last workgroup
+  unsigned* done1;           // [B]          (state) workgroups of the histogram pass that have finished, per pair
   int* thr;                  // [R]
-  unsigned* ncand;           // [R]
-  unsigned* phist;           // [B][NBINS]   histogram of p itself (analytic threshold)
-  int* redo;                 // [B] per pair: set when one of its rows collected fewer than k candidates above an analytic threshold
-                             //     or a workgroup's queue overflowed -- the exact passes then redo THAT pair only (the others keep
-                             //     their skip-sampler draws: a pair's result never depends on its batch)
   unsigned long long* cand;  // [R][CAND_MAX]
   int* invalid;              // [1] or null
   int pair_base;             // global index of pair 0 of this call (keys the Philox streams)
@@ -112,30 +115,23 @@ __device__ __forceinline__ void row_keys(const float* __restrict__ noise, unsign
 // round trip whenever any of its 256 keys is a candidate -- inside the Philox loop that was ~25 % of the pass.
 constexpr int LCAP = 960;   // LDS candidate slots per row and block (expected ~25 at k = 2048, 128 blocks); overflow goes direct
 
-template <int PASS, bool REDO = false>  // 0: histogram, 1: collect; REDO: part of the exact fallback, runs only for pairs whose w.redo is set
+// (the every-cell collect pass: injected noise -- tests -- and more rows per pair than the generators below are built for)
 __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restrict__ p, const float* __restrict__ noise,
                                                            unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
                                                            const unsigned long long* __restrict__ offp, TopkWork w,
                                                            int rows_per_pair, long long ncell) {
-  __shared__ unsigned sh[RG * NBINS];   // pass 0: key histograms; pass 1: [RG][LCAP] candidates (2 words each) + counters
+  __shared__ unsigned long long lbuf[RG * LCAP];
   __shared__ unsigned lcount[RG], lbase[RG];
-  if (REDO && w.redo[blockIdx.z] == 0) return;
   add_device_offset(off_lo, off_hi, offp);
   const int b = blockIdx.z, grp = blockIdx.y;
   const long long per = (ncell + gridDim.x - 1) / gridDim.x;
   const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
-  unsigned long long* lbuf = (unsigned long long*)sh;   // [RG][LCAP]
-  static_assert(RG * LCAP * 8 <= RG * NBINS * 4, "candidate buffer must fit the histogram array");
   int thr[RG];
-  if (PASS == 0) {
-    for (int i = threadIdx.x; i < RG * NBINS; i += 256) sh[i] = 0;
-  } else {
-    if (threadIdx.x < RG) lcount[threadIdx.x] = 0;
+  if (threadIdx.x < RG) lcount[threadIdx.x] = 0;
 #pragma unroll
-    for (int q = 0; q < RG; ++q) {
-      const int r = grp * RG + q;
-      thr[q] = r < rows_per_pair ? w.thr[b * rows_per_pair + r] : NBINS;
-    }
+  for (int q = 0; q < RG; ++q) {
+    const int r = grp * RG + q;
+    thr[q] = r < rows_per_pair ? w.thr[b * rows_per_pair + r] : NBINS;
   }
   __syncthreads();
   const float* pb = p + (long long)b * ncell;
@@ -150,9 +146,7 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
       if (r >= rows_per_pair) continue;
       const unsigned bits = __float_as_uint(key[q]);
       const int bin = (int)((bits & 0x7fffffffu) >> 20);
-      if (PASS == 0) {
-        atomicAdd(&sh[q * NBINS + bin], 1u);
-      } else if (bin >= thr[q]) {
+      if (bin >= thr[q]) {
         const unsigned long long item = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
         const unsigned ls = atomicAdd(&lcount[q], 1u);
         if (ls < (unsigned)LCAP) {
@@ -166,28 +160,111 @@ __global__ __launch_bounds__(256) void exprace_scan_kernel(const float* __restri
     }
   }
   __syncthreads();
-  if (PASS == 0) {
-    for (int i = threadIdx.x; i < RG * NBINS; i += 256) {
-      const int q = i / NBINS, r = grp * RG + q;
-      if (sh[i] && r < rows_per_pair) atomicAdd(&w.hist[((long long)b * rows_per_pair + r) * NBINS + (i % NBINS)], sh[i]);
-    }
-  } else {
-    if (threadIdx.x < RG) {
-      const int q = threadIdx.x, r = grp * RG + q;
-      const unsigned nloc = min(lcount[q], (unsigned)LCAP);
-      lbase[q] = (r < rows_per_pair && nloc) ? atomicAdd(&w.ncand[b * rows_per_pair + r], nloc) : 0u;
+  if (threadIdx.x < RG) {
+    const int q = threadIdx.x, r = grp * RG + q;
+    const unsigned nloc = min(lcount[q], (unsigned)LCAP);
+    lbase[q] = (r < rows_per_pair && nloc) ? atomicAdd(&w.ncand[b * rows_per_pair + r], nloc) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < RG; ++q) {
+    const int r = grp * RG + q;
+    if (r >= rows_per_pair) continue;
+    const unsigned nloc = min(lcount[q], (unsigned)LCAP), base = lbase[q];
+    const long long row = (long long)b * rows_per_pair + r;
+    for (unsigned i = threadIdx.x; i < nloc; i += 256)
+      if (base + i < (unsigned)CAND_MAX) w.cand[row * CAND_MAX + base + i] = lbuf[q * LCAP + i];
+  }
+}
+
+// ---- exact fallback: ONE workgroup does RG rows of a pair start to finish (early exit unless the pair's `redo` is set: the
+// common case pays one launch of idle workgroups).  Pass 0: key histograms of its rows in LDS; the largest bin whose tail holds
+// >= k keys per row; pass 1: the keys at or above it are the candidates -- the exact top-k whatever the distribution of p or of
+// the (injected) noise.  Slow by design (a workgroup walks all cells twice: ~1 ms at 3.8 M cells); it never runs on a matcher's
+// output, it is what makes the result EXACT for adversarial inputs.
+__global__ __launch_bounds__(1024) void exprace_fallback_kernel(const float* __restrict__ p, const float* __restrict__ noise,
+                                                                unsigned k0, unsigned k1, unsigned off_lo, unsigned off_hi,
+                                                                const unsigned long long* __restrict__ offp, TopkWork w,
+                                                                int rows_per_pair, long long ncell, int k) {
+  __shared__ unsigned sh[RG * NBINS];
+  __shared__ unsigned part[256];
+  __shared__ int thr_s[RG];
+  __shared__ unsigned cnt_s[RG];
+  const int b = blockIdx.y, grp = blockIdx.x, t = threadIdx.x;
+  // does this pair need the fallback?  A queue of the generator overflowed (`redo`, raised there), or one of the pair's rows fell
+  // short of k candidates although its threshold was not "everything", or overflowed its candidate buffer (noise that is not
+  // Exp(1)-distributed can do either).  Every workgroup of the pair evaluates the same rows_per_pair counts: no hand-over between
+  // workgroups, no check launch, no tail in the collect pass (round 6).
+  __shared__ int need_s;
+  if (t == 0) need_s = w.redo[b];
+  __syncthreads();
+  if (t < rows_per_pair) {
+    const unsigned nc = w.ncand[b * rows_per_pair + t];
+    if ((w.thr[b * rows_per_pair + t] > 0 && nc < (unsigned)k) || nc > (unsigned)CAND_MAX) atomicOr(&need_s, 1);
+  }
+  __syncthreads();
+  if (need_s == 0) return;
+  add_device_offset(off_lo, off_hi, offp);
+  for (int i = t; i < RG * NBINS; i += 1024) sh[i] = 0;
+  if (t < RG) cnt_s[t] = 0;
+  __syncthreads();
+  const float* pb = p + (long long)b * ncell;
+  for (long long c = t; c < ncell; c += 1024) {
+    const float pv = pb[c];
+    if (!(pv > 0.f) || isinf(pv)) continue;
+    float key[RG];
+    row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key, w.pair_base);
+#pragma unroll
+    for (int q = 0; q < RG; ++q)
+      if (grp * RG + q < rows_per_pair) atomicAdd(&sh[q * NBINS + (int)((__float_as_uint(key[q]) & 0x7fffffffu) >> 20)], 1u);
+  }
+  __syncthreads();
+  // per row: largest bin tb with count(bins >= tb) >= k (0 if fewer than k non-zero keys); thread t < 256 owns 8 bins
+  for (int q = 0; q < RG; ++q) {
+    const unsigned* h = sh + q * NBINS;
+    if (t < 256) {
+      unsigned loc = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) loc += h[t * 8 + i];
+      part[t] = loc;
     }
     __syncthreads();
+    if (t == 0) {
+      unsigned run = 0;
+      int tb = 0;
+      for (int s8 = 255; s8 >= 0; --s8) {
+        if (run + part[s8] >= (unsigned)k) {
+          for (int i = 7; i >= 0; --i) {
+            run += h[s8 * 8 + i];
+            if (run >= (unsigned)k) { tb = s8 * 8 + i; break; }
+          }
+          break;
+        }
+        run += part[s8];
+      }
+      thr_s[q] = tb;
+      if (grp * RG + q < rows_per_pair) w.thr[b * rows_per_pair + grp * RG + q] = tb;
+    }
+    __syncthreads();
+  }
+  for (long long c = t; c < ncell; c += 1024) {
+    const float pv = pb[c];
+    if (!(pv > 0.f) || isinf(pv)) continue;
+    float key[RG];
+    row_keys(noise, k0, k1, off_lo, off_hi, pv, c, ncell, b, rows_per_pair, grp, key, w.pair_base);
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int r = grp * RG + q;
       if (r >= rows_per_pair) continue;
-      const unsigned nloc = min(lcount[q], (unsigned)LCAP), base = lbase[q];
-      const long long row = (long long)b * rows_per_pair + r;
-      for (unsigned i = threadIdx.x; i < nloc; i += 256)
-        if (base + i < (unsigned)CAND_MAX) w.cand[row * CAND_MAX + base + i] = lbuf[q * LCAP + i];
+      const unsigned bits = __float_as_uint(key[q]);
+      if ((int)((bits & 0x7fffffffu) >> 20) < thr_s[q]) continue;
+      const unsigned slot = atomicAdd(&cnt_s[q], 1u);
+      if (slot < (unsigned)CAND_MAX)
+        w.cand[((long long)b * rows_per_pair + r) * CAND_MAX + slot] = ((unsigned long long)bits << 32) | (unsigned)(0xffffffffu - (unsigned)c);
     }
   }
+  __syncthreads();
+  if (t < RG && grp * RG + t < rows_per_pair) w.ncand[b * rows_per_pair + grp * RG + t] = cnt_s[t];   // replaces what the generator counted
 }
 
 // ---- Philox collect pass with a 6-bit pre-filter ---------------------------------------------------------------------
@@ -221,7 +298,7 @@ __global__ __launch_bounds__(256) void exprace_prefilter_kernel(const float* __r
   const long long per = (ncell + gridDim.x - 1) / gridDim.x;
   const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
   const unsigned zb = (unsigned)(b + w.pair_base) * 512u;
-  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (exprace_athresh_kernel)
+  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (the tail of exprace_phist_kernel)
   const float T = __uint_as_float((unsigned)thr0 << 20);
   const float pfast = 0.0155f * T;                     // -ln(1 - 2^-6) = 0.015748: margin for the 1-ulp log / rcp
   const float pnever = 2.9e-8f * T;                    // smallest e: -ln(1 - 2^-25) = 2.98e-8
@@ -357,7 +434,7 @@ __global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restri
   const int nb = (int)min((long long)SK_RANGE, w.nblk - blk0);
   const long long cbase = blk0 * SK_CELLS;
   const unsigned zb = (unsigned)(b + w.pair_base) * 512u;
-  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (exprace_athresh_kernel)
+  const int thr0 = w.thr[b * rows_per_pair];          // one analytic threshold per pair (the tail of exprace_phist_kernel)
   const float T = __uint_as_float((unsigned)thr0 << 20);
   const float invT = T > 0.f ? 1.f / T : __builtin_inff();   // T = 0: "collect every positive cell"
   const float* pb = p + (long long)b * ncell;
@@ -506,35 +583,6 @@ __global__ __launch_bounds__(256) void exprace_skip_kernel(const float* __restri
   }
 }
 
-// one block per row: largest bin t with count(bins >= t) >= k (t = 0 if fewer than k non-zero keys)
-__global__ __launch_bounds__(256) void exprace_threshold_kernel(TopkWork w, int k, int rows_per_pair) {
-  __shared__ unsigned part[256];
-  const int row = blockIdx.x, t = threadIdx.x;
-  if (w.redo[row / rows_per_pair] == 0) return;   // exact fallback only, per pair
-  const unsigned* h = w.hist + (long long)row * NBINS;
-  // thread t owns bins [t*8, t*8+8); suffix sums from the top
-  unsigned loc = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) loc += h[t * 8 + i];
-  part[t] = loc;
-  __syncthreads();
-  if (t == 0) {
-    unsigned run = 0;
-    int tb = 0;
-    for (int s = 255; s >= 0; --s) {
-      if (run + part[s] >= (unsigned)k) {
-        for (int i = 7; i >= 0; --i) {
-          run += h[s * 8 + i];
-          if (run >= (unsigned)k) { tb = s * 8 + i; break; }
-        }
-        break;
-      }
-      run += part[s];
-    }
-    w.thr[row] = tb;
-  }
-}
-
 // ---- analytic threshold --------------------------------------------------------------------------------------
 // The number of race keys p_i / E_i (E_i ~ Exp(1)) above T is a sum of independent Bernoulli(1 - exp(-p_i / T)): its
 // mean is a function of p alone, shared by all draws of a pair.  So instead of generating all rows_per_pair x ncell
@@ -552,51 +600,22 @@ __device__ __forceinline__ float row16_max(float m) {   // maximum over the lane
 // histogram of p (analytic threshold) and, in the same read, the largest valid p of every 16 consecutive cells (w.pmax: the
 // rate bound of the skip sampler below).  A workgroup's cell range starts at a multiple of 256, a wave reads 64 consecutive
 // cells per iteration: a 16-cell block is one DPP row.
-__global__ __launch_bounds__(256) void exprace_phist_kernel(const float* __restrict__ p, TopkWork w, long long ncell) {
-  __shared__ unsigned sh[NBINS];
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < NBINS; i += 256) sh[i] = 0;
-  __syncthreads();
-  const long long per = ((ncell + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
-  const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
-  const float* pb = p + (long long)b * ncell;
-  float* pm = w.pmax + (long long)b * w.nblk;
-  bool bad = false;
-  for (long long base = c0; base < c1; base += 1024) {   // (uniform trip count: the DPP reduction needs whole rows)
-    float pv[4];
-    bool in[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {   // four loads in flight per thread
-      const long long c = base + u * 256 + threadIdx.x;
-      in[u] = c < c1;
-      pv[u] = in[u] ? pb[c] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long c = base + u * 256 + threadIdx.x;
-      bad |= !(pv[u] >= 0.f) || isinf(pv[u]);
-      const bool ok = pv[u] > 0.f && !isinf(pv[u]);
-      if (ok) atomicAdd(&sh[__float_as_uint(pv[u]) >> 20], 1u);
-      const float m = row16_max(ok ? pv[u] : 0.f);
-      if ((threadIdx.x & 15) == 0 && in[u]) pm[c >> 4] = m;
-    }
-  }
-  if (bad && w.invalid) atomicOr(w.invalid, 1);
-  __syncthreads();
-  for (int i = threadIdx.x; i < NBINS; i += 256)
-    if (sh[i]) atomicAdd(&w.phist[(long long)b * NBINS + i], sh[i]);
-}
-
-// one block per pair: largest key bin t whose expected tail count sum_bins h[pb] * (1 - exp(-p_mid(pb) / T_t)) >= need
-__global__ __launch_bounds__(256) void exprace_athresh_kernel(TopkWork w, int rows_per_pair, float need) {
-  __shared__ float red[256];
-  const int b = blockIdx.x, t = threadIdx.x;
+// Round 6: (a) for large matrices (>= 2^20 cells) only every fourth 256-cell group enters the histogram, weighted 4: the threshold
+// only has to land the expected candidate count near 1.25 k (any T that leaves every row between k and CAND_MAX candidates gives
+// the exact top-k of the keys; a shortfall raises `redo`), while the LDS atomics -- most cells share a handful of bins, i.e. one
+// address per wave -- were the pass's bottleneck, not the read; the rule depends on ncell alone (never on the batch);
+// (b) the threshold search is the TAIL of this kernel: the last workgroup of a pair to finish reduces the pair's histogram
+// (one launch less in front of the collect pass, and the pairs' searches overlap the other pairs' reads).
+// one pair's analytic threshold: largest key bin t whose expected tail count sum_bins h[pb] * (1 - exp(-p_mid(pb) / T_t)) >= need
+__device__ __forceinline__ void athresh_block(const TopkWork& w, int b, int rows_per_pair, float need, float* red) {
+  const int t = threadIdx.x;
   float hp[8], pm[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int bin = t * 8 + i;
-    hp[i] = (float)w.phist[(long long)b * NBINS + bin];
+    hp[i] = (float)__hip_atomic_load(&w.phist[(long long)b * NBINS + bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pm[i] = __uint_as_float(((unsigned)bin << 20) | (1u << 19));   // middle of the bin
+    w.phist[(long long)b * NBINS + bin] = 0;                        // self-cleaning state (TopkWork)
   }
   auto expected = [&](int tb) {   // block-wide; every thread returns the total
     const float T = __uint_as_float((unsigned)tb << 20);           // lower edge of key bin tb
@@ -626,16 +645,82 @@ __global__ __launch_bounds__(256) void exprace_athresh_kernel(TopkWork w, int ro
   for (int r = t; r < rows_per_pair; r += 256) w.thr[b * rows_per_pair + r] = lo;
 }
 
-// raise `redo` if a row fell short of k candidates although its threshold was not "everything", or overflowed its
-// candidate buffer (noise that is not Exp(1)-distributed can do either)
-__global__ void exprace_check_kernel(TopkWork w, int R, int k, int rows_per_pair) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < R && ((w.thr[row] > 0 && w.ncand[row] < (unsigned)k) || w.ncand[row] > (unsigned)CAND_MAX))
-    atomicOr(&w.redo[row / rows_per_pair], 1);
-}
-__global__ void exprace_rezero_kernel(TopkWork w, int R, int rows_per_pair) {   // before the exact collect pass of the fallback
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < R && w.redo[row / rows_per_pair] != 0) w.ncand[row] = 0;
+__global__ __launch_bounds__(256) void exprace_phist_kernel(const float* __restrict__ p, TopkWork w, long long ncell, int rows_per_pair,
+                                                            float need) {
+  __shared__ unsigned sh[NBINS];
+  __shared__ float red[256];
+  __shared__ bool last_wg;
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < NBINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  const long long per = ((ncell + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long long c0 = blockIdx.x * per, c1 = min(ncell, c0 + per);
+  const float* pb = p + (long long)b * ncell;
+  float* pm = w.pmax + (long long)b * w.nblk;
+  const bool sub = ncell >= (1LL << 20);   // subsampled histogram (see above)
+  bool bad = false;
+  if ((ncell & 3) == 0 && ((uintptr_t)p & 15) == 0) {
+    // 16-byte loads, four per thread in flight (64 B per lane: with 4-byte loads the pass had 32 KB per CU in flight and ran at
+    // 3 TB/s -- latency-bound, not bandwidth-bound); a 16-cell block is four consecutive lanes: two quad-permute steps
+    for (long long base = c0; base < c1; base += 4096) {
+      f32x4 pv[4];
+      long long c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c[u] = base + (u * 256 + threadIdx.x) * 4;
+        pv[u] = c[u] < c1 ? __builtin_nontemporal_load((const f32x4*)(pb + c[u])) : f32x4{0.f, 0.f, 0.f, 0.f};   // (c1 % 4 == 0)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = pv[u][e];
+          bad |= !(v >= 0.f) || isinf(v);
+          const bool ok = v > 0.f && !isinf(v);
+          if (ok && (!sub || u == 0)) atomicAdd(&sh[__float_as_uint(v) >> 20], sub ? 4u : 1u);
+          m = fmaxf(m, ok ? v : 0.f);
+        }
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+        if ((threadIdx.x & 3) == 0 && c[u] < c1) pm[c[u] >> 4] = m;
+      }
+    }
+  } else {
+    for (long long base = c0; base < c1; base += 1024) {   // (uniform trip count: the DPP reduction needs whole rows)
+      float pv[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {   // four loads in flight per thread
+        const long long c = base + u * 256 + threadIdx.x;
+        in[u] = c < c1;
+        pv[u] = in[u] ? pb[c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long c = base + u * 256 + threadIdx.x;
+        bad |= !(pv[u] >= 0.f) || isinf(pv[u]);
+        const bool ok = pv[u] > 0.f && !isinf(pv[u]);
+        if (ok && (!sub || u == 0)) atomicAdd(&sh[__float_as_uint(pv[u]) >> 20], sub ? 4u : 1u);
+        const float m = row16_max(ok ? pv[u] : 0.f);
+        if ((threadIdx.x & 15) == 0 && in[u]) pm[c >> 4] = m;
+      }
+    }
+  }
+  if (bad && w.invalid) atomicOr(w.invalid, 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NBINS; i += 256)
+    if (sh[i]) atomicAdd(&w.phist[(long long)b * NBINS + i], sh[i]);
+  // ---- tail: the pair's last workgroup turns the histogram into the pair's threshold (hand-over by device-scope atomics only,
+  // performed where every XCD sees them and complete -- waited for below -- before this workgroup's arrival is counted; the last
+  // workgroup reads them with device-scope loads.  No __threadfence(): its L2 write-back, once per workgroup, cost four times the pass)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last_wg = atomicAdd(&w.done1[b], 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (!last_wg) return;
+  athresh_block(w, b, rows_per_pair, need, red);
+  if (threadIdx.x == 0) w.done1[b] = 0;   // self-cleaning state (TopkWork)
 }
 
 // one block per row: sort the candidates (key desc, index asc), emit the top k.
@@ -665,6 +750,10 @@ __device__ __forceinline__ void select_thread_pass(unsigned long long (&v)[E], i
   }
 }
 
+constexpr int SEL_T = 1024;       // threads of the select kernel (512 threads with 8 slots each and 32 KiB of LDS -- every row of a 32-pair
+                                  // batch resident at once -- measured 100 us against 89: profiles/r06f_sampler_kernel_stats.txt)
+constexpr int SEL_LDS = 8192;     // slots of its LDS exchange buffer (= CAND_MAX)
+
 template <int E>
 __device__ __forceinline__ void select_sort(unsigned long long (&v)[E], unsigned long long* keys, int np2, int t) {
   for (int kk = 2; kk <= np2; kk <<= 1) {
@@ -672,7 +761,8 @@ __device__ __forceinline__ void select_sort(unsigned long long (&v)[E], unsigned
       if (j < E) {
         if (j == 1) select_thread_pass<E, 1>(v, kk, t);
         else if (j == 2) select_thread_pass<E, 2>(v, kk, t);
-        else select_thread_pass<E, 4>(v, kk, t);
+        else if (j == 4) select_thread_pass<E, 4>(v, kk, t);
+        else select_thread_pass<E, 8>(v, kk, t);
       } else if (j < 64 * E) {
         const int lm = j / E;            // lane distance
 #pragma unroll
@@ -704,7 +794,7 @@ __device__ __forceinline__ void select_sort(unsigned long long (&v)[E], unsigned
 }
 
 template <int E>
-__device__ __forceinline__ void select_run(const unsigned long long* __restrict__ cand, unsigned long long* keys, int nc, int np2,
+__device__ __forceinline__ void select_run(unsigned long long* cand, unsigned long long* keys, int nc, int np2,
                                            int* __restrict__ out, int take) {
   const int t = threadIdx.x;
   unsigned long long v[E];
@@ -721,16 +811,16 @@ __device__ __forceinline__ void select_run(const unsigned long long* __restrict_
   }
 }
 
-__global__ __launch_bounds__(1024) void exprace_select_kernel(const float* __restrict__ p, TopkWork w, int* __restrict__ idx,
-                                                              int* __restrict__ cnt, int rows_per_pair, long long ncell,
-                                                              int k) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+__global__ __launch_bounds__(SEL_T) void exprace_select_kernel(const float* __restrict__ p, TopkWork w, int* __restrict__ idx,
+                                                               int* __restrict__ cnt, int rows_per_pair, long long ncell,
+                                                               int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // [SEL_LDS]
   const int row = blockIdx.x;
   const unsigned nc_raw = w.ncand[row];
   const int nc = (int)min(nc_raw, (unsigned)CAND_MAX);
-  int np2 = 1024;                    // at least one slot per thread (E = 1); CAND_MAX = 8192 -> E <= 8
+  int np2 = SEL_T;                   // at least one slot per thread (E = 1); CAND_MAX = 8192 -> E <= 8
   while (np2 < nc) np2 <<= 1;
-  const unsigned long long* cand = w.cand + (long long)row * CAND_MAX;
+  unsigned long long* cand = w.cand + (long long)row * CAND_MAX;
   const int take = min(nc, k);
   int* out = idx + (long long)row * k;
   if (np2 == 1024) select_run<1>(cand, keys, nc, np2, out, take);        // (workgroup-uniform)
@@ -748,10 +838,12 @@ __global__ __launch_bounds__(1024) void exprace_select_kernel(const float* __res
       for (; f < k; ++f) idx[(long long)row * k + f] = 0;
     }
   }
-}
-
-__global__ void zero_u32_kernel(unsigned* p, long long n) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+  // self-cleaning state (TopkWork): this workgroup was the last reader of its row's count, the chain's last kernel of the pair's `redo`
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    w.ncand[row] = 0;
+    if (row % rows_per_pair == 0) w.redo[row / rows_per_pair] = 0;
+  }
 }
 
 // ---- gather + back-projection -----------------------------------------------------------------------
@@ -1393,15 +1485,18 @@ __global__ void finalize_kernel(float* R, float* t, float* conf, const int* inva
 
 int g_exprace_mode = 0;   // dev (mk_exprace_set_mode): 0 = skip sampler, 1 = the 6-bit pre-filter pass
 
+// bytes of the self-cleaning state at the head of the workspace (TopkWork)
+long long topk_state_bytes(long long R, long long B) { return (R * 4 + B * 4 + B * NBINS * 4 + B * 4 + 15) / 16 * 16; }
+
 TopkWork carve(void* work, int R, int B, long long ncell) {
   TopkWork w;
   char* p = (char*)work;
-  w.hist = (unsigned*)p;  p += (size_t)R * NBINS * 4;
-  w.thr = (int*)p;        p += (size_t)R * 4;
   w.ncand = (unsigned*)p; p += (size_t)R * 4;
-  w.phist = (unsigned*)p; p += (size_t)B * NBINS * 4;
   w.redo = (int*)p;       p += (size_t)B * 4;
-  p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  w.phist = (unsigned*)p; p += (size_t)B * NBINS * 4;
+  w.done1 = (unsigned*)p; p += (size_t)B * 4;
+  p = (char*)work + topk_state_bytes(R, B);
+  w.thr = (int*)p;        p += ((size_t)R * 4 + 15) / 16 * 16;
   w.cand = (unsigned long long*)p;  p += (size_t)R * CAND_MAX * 8;
   w.nblk = (ncell + SK_CELLS - 1) / SK_CELLS;
   w.pmax = (float*)p;
@@ -1415,8 +1510,9 @@ extern "C" {
 long long mk_exprace_topk_work_bytes(int B, int rows_per_pair, int k, long long ncell) {
   (void)k;
   const long long R = (long long)B * rows_per_pair;
-  return R * NBINS * 4 + R * 8 + (long long)B * NBINS * 4 + 4LL * B + 16 + R * CAND_MAX * 8 + (long long)B * ((ncell + SK_CELLS - 1) / SK_CELLS) * 4;
+  return topk_state_bytes(R, B) + (R * 4 + 15) / 16 * 16 + R * CAND_MAX * 8 + (long long)B * ((ncell + SK_CELLS - 1) / SK_CELLS) * 4;
 }
+long long mk_exprace_topk_state_bytes(int B, int rows_per_pair) { return topk_state_bytes((long long)B * rows_per_pair, B); }
 int mk_exprace_set_mode(int mode) {
   MK_CHECK_ARG(mode == 0 || mode == 1, "mk_exprace_set_mode: 0 (skip sampler) or 1 (pre-filter pass)");
   g_exprace_mode = mode;
@@ -1443,9 +1539,6 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   TopkWork w = carve(work, R, B, ncell);
   w.invalid = invalid;
   w.pair_base = pair_base;
-  const long long nz = (long long)R * NBINS + 2LL * R + (long long)B * NBINS + B;
-  hipLaunchKernelGGL(zero_u32_kernel, dim3(256), dim3(256), 0, st, w.hist, nz);  // hist | thr | ncand | phist | redo are contiguous
-  MK_CHECK_LAUNCH();
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), ol = (unsigned)offset, oh = (unsigned)(offset >> 32);
   const int groups = (rows_per_pair + RG - 1) / RG;
   // cell blocks per pair: 128 at the bench batch; small batches (one pair: 128 workgroups on a 256-CU part, each walking 29 k
@@ -1454,11 +1547,10 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
   int cb = CELL_BLOCKS;
   while (cb < 1024 && (long long)B * cb < 2048) cb *= 2;
   if ((long long)cb * 256 > ncell) cb = (int)((ncell + 255) / 256);
-  dim3 grid(cb, groups, B);
-  // analytic threshold from the histogram of p, then ONE noise pass (collect)
-  hipLaunchKernelGGL(exprace_phist_kernel, dim3(cb, B), dim3(256), 0, st, p, w, ncell);
-  MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(exprace_athresh_kernel, dim3(B), dim3(256), 0, st, w, rows_per_pair, 1.25f * (float)k);
+  // The chain is FOUR launches (round 6; ten before): histogram of p + the 16-cell maxima with the analytic threshold as its
+  // tail -> ONE noise pass (collect) -> the exact fallback (its workgroups check their pair's rows and leave unless the pair
+  // came up short) -> select.  No zero-fill: the state words clean themselves (TopkWork).
+  hipLaunchKernelGGL(exprace_phist_kernel, dim3(cb, B), dim3(256), 0, st, p, w, ncell, rows_per_pair, 1.25f * (float)k);
   MK_CHECK_LAUNCH();
   // the block-local cell index must fit 16 bits of a queue entry: more cell blocks for very large matrices
   int pcb = cb;
@@ -1467,22 +1559,21 @@ int mk_exprace_topk(const float* p, const float* noise, unsigned long long seed,
     // (the walk geometry is a function of ncell alone: a pair's draws do not depend on the batch)
     hipLaunchKernelGGL(exprace_skip_kernel, dim3((unsigned)((w.nblk + SK_RANGE - 1) / SK_RANGE), (rows_per_pair + SK_ROWS - 1) / SK_ROWS, B),
                        dim3(256), 0, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
-  } else if (!noise && rows_per_pair <= PF_MAXROWS) {
-    const size_t lds = (size_t)rows_per_pair * PF_LCAP * 8 + (size_t)PF_QCAP * 4;
-    hipLaunchKernelGGL(exprace_prefilter_kernel, dim3(pcb, B), dim3(256), lds, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair,
-                       ncell);
   } else {
-    hipLaunchKernelGGL((exprace_scan_kernel<1, false>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+    if (!noise && rows_per_pair <= PF_MAXROWS) {
+      const size_t lds = (size_t)rows_per_pair * PF_LCAP * 8 + (size_t)PF_QCAP * 4;
+      hipLaunchKernelGGL(exprace_prefilter_kernel, dim3(pcb, B), dim3(256), lds, st, p, k0, k1, ol, oh, offset_dev, w, rows_per_pair,
+                         ncell);
+    } else {
+      hipLaunchKernelGGL(exprace_scan_kernel, dim3(cb, groups, B), dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+    }
   }
   MK_CHECK_LAUNCH();
-  // exact fallback (runs only if a row came up short: never observed, kept for adversarial inputs / injected noise)
-  hipLaunchKernelGGL(exprace_check_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, k, rows_per_pair);
-  hipLaunchKernelGGL((exprace_scan_kernel<0, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
-  hipLaunchKernelGGL(exprace_threshold_kernel, dim3(R), dim3(256), 0, st, w, k, rows_per_pair);
-  hipLaunchKernelGGL(exprace_rezero_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, R, rows_per_pair);
-  hipLaunchKernelGGL((exprace_scan_kernel<1, true>), grid, dim3(256), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair, ncell);
+  // exact fallback (runs only if a row came up short: never observed on a matcher's output, kept for adversarial inputs / injected noise)
+  hipLaunchKernelGGL(exprace_fallback_kernel, dim3(groups, B), dim3(1024), 0, st, p, noise, k0, k1, ol, oh, offset_dev, w, rows_per_pair,
+                     ncell, k);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(1024), (size_t)CAND_MAX * 8, st, p, w, idx, cnt, rows_per_pair, ncell,
+  hipLaunchKernelGGL(exprace_select_kernel, dim3(R), dim3(SEL_T), (size_t)SEL_LDS * 8, st, p, w, idx, cnt, rows_per_pair, ncell,
                      k);
   MK_CHECK_LAUNCH();
   return MK_OK;

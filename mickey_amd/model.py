@@ -313,7 +313,8 @@ class MickeyRelativePose(nn.Module):
         # data["pair_base"] (optional, int): global index of this batch's first pair -- a rank of a sharded batch passes its
         # shard offset so that the poses do not depend on the sharding (mickey_amd.distributed.shard_batch sets it)
         sol = pipeline.solve(self.cfg, data["final_scores"], data["kps0"], data["depth_kp0"], data["kps1"], data["depth_kp1"],
-                             K0, K1, seed=self.seed, offset=0, offset_dev=self._ctr, pair_base=int(data.get("pair_base", 0)))
+                             K0, K1, seed=self.seed, offset=0, offset_dev=self._ctr, pair_base=int(data.get("pair_base", 0)),
+                             ws=self._ws)
         if return_inliers:
             return sol["R"], sol["t"], sol["inliers"], pipeline.inliers_list(sol)
         return sol["R"], sol["t"], sol["inliers"]

@@ -392,15 +392,26 @@ def exprace_set_mode(mode):
     call("mk_exprace_set_mode", int(mode))
 
 
-def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None, pair_base=0):
-    """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair])."""
+def exprace_work(B, rows_per_pair, k, ncell, device):
+    """Workspace of mk_exprace_topk with its self-cleaning state zeroed (mickey_hip.h): allocate ONCE per shape and stream and
+    hand it to every exprace_topk call -- a call leaves the state zero, so no zero-fill launch stands in front of the chain."""
+    work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k, ncell),), device=device, dtype=torch.uint8)
+    work[:query("mk_exprace_topk_state_bytes", B, rows_per_pair)].zero_()
+    return work
+
+
+def exprace_topk(p, rows_per_pair, k, noise=None, seed=0, offset=0, invalid=None, offset_dev=None, pair_base=0, work=None):
+    """p fp32 [B, ncell] -> (idx int32 [B*rows_per_pair, k], cnt int32 [B*rows_per_pair]).  work: exprace_work(...) kept by the
+    caller across calls (None: allocated and zeroed here -- one more launch)."""
     p, noise = _c(p, noise)
     _chk(p, torch.float32)
     B, ncell = p.shape
     dev = p.device
     idx = torch.empty((B * rows_per_pair, k), device=dev, dtype=torch.int32)
     cnt = torch.empty((B * rows_per_pair,), device=dev, dtype=torch.int32)
-    work = torch.empty((query("mk_exprace_topk_work_bytes", B, rows_per_pair, k, ncell),), device=dev, dtype=torch.uint8)
+    if work is None:
+        work = exprace_work(B, rows_per_pair, k, ncell, dev)
+    assert work.numel() >= query("mk_exprace_topk_work_bytes", B, rows_per_pair, k, ncell)
     call("mk_exprace_topk", ptr(p), ptr(noise), int(seed), int(offset), ptr(offset_dev), ptr(idx), ptr(cnt), ptr(invalid), ptr(work),
          B, rows_per_pair, ncell, k, int(pair_base), stream())
     return idx, cnt

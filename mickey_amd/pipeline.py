@@ -284,7 +284,7 @@ def match(W, cfg, dsc0, dsc1, scr0, scr1, lean=False):
 
 
 def solve(cfg, final_scores, kps0, depth0, kps1, depth1, K0, K1, seed=0, offset=0, noise_outer=None, noise_inner=None,
-          idx3_in=None, debug=False, offset_dev=None, pair_base=0):
+          idx3_in=None, debug=False, offset_dev=None, pair_base=0, ws=None):
     """reference probabilisticProcrustes.py:183-348 on device.  Returns a dict with R [B,3,3], t [B,1,3],
     inliers [B,1] and the intermediates needed for the inlier list.  pair_base = global index of pair 0 (keys the
     Philox streams: sharding a batch over calls / GPUs does not change any pair's draws)."""
@@ -295,8 +295,16 @@ def solve(cfg, final_scores, kps0, depth0, kps1, depth1, K0, K1, seed=0, offset=
     B, n0, n1 = final_scores.shape
     dev = final_scores.device
     invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
+    # the sampler's workspace lives in the model's Workspace (ws) like every other buffer of a forward: zeroed once, self-cleaning
+    # afterwards (mickey_hip.h); one model is one forward at a time
+    work = None
+    if ws is not None:
+        key = ("exprace_work", B, it_m, ns, n0 * n1)
+        work = ws.bufs.get(key)
+        if work is None or work.device != dev:
+            work = ws.bufs[key] = ops.exprace_work(B, it_m, ns, n0 * n1, dev)
     idx, cnt = ops.exprace_topk(final_scores.reshape(B, n0 * n1), it_m, ns, noise=noise_outer, seed=seed, offset=offset,
-                                invalid=invalid, offset_dev=offset_dev, pair_base=pair_base)
+                                invalid=invalid, offset_dev=offset_dev, pair_base=pair_base, work=work)
     X, Y, w, corr = ops.gather_backproject(idx, final_scores, kps0, depth0, kps1, depth1, K0, K1, it_m)
     Rh, th, score, idx3 = ops.ransac_hypotheses(X, Y, w, it_r, float(P["TH_SOFT_INLIER"]), noise3=noise_inner,
                                                 idx3_in=idx3_in, seed=seed, offset=offset + 1, offset_dev=offset_dev,

@@ -34,9 +34,13 @@ def test_last_stdout_line_is_small_and_complete(tmp_path):
     assert roof["bound"] == "mfma" and 0.0 < roof["frac"] < 1.0 and roof["launches"] > 0 and roof["avg_launch_ms"] > 0
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-2)
     cb = line["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "1 pair" in cb["sample"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "1 pair" in cb["sample"] and "median of 3" in cb["sample"]
+    assert set(cb["stage_seconds"]) == {"encoder", "heads", "matcher", "solver", "total"}
+    assert line["sustained_60"] > 0
     assert 1 <= len(line["stages"]) <= 6
     assert line["value_ref_precision"] > 0 and line["single_pair_ms"] > 0
     full = json.load(open(detail))
     assert "legs" in full and "ref_split" in full["legs"] and len(full["roofline"]["stages"]) >= 6
+    assert full["sustained"]["steps"] == 60 and len(full["cpu_baseline"]["runs_total_seconds"]) == 3
+    assert full["cpu_baseline"]["threads_probe"]["measured_once"]["seconds_threads_256"] > 100   # (the all-cores probe is opt-in)
     assert "split" in full["legs"]["ref_split"]["heads_operands"]

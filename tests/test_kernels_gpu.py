@@ -126,6 +126,42 @@ def test_persistent_gemm_is_bit_identical(which, dtype):
     ops.gemm_set_tile(600)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,K,last", [(384, 384, False), (384, 1536, False), (384, 1536, True), (384, 256, False), (1024, 256, False)])
+def test_persistent_gemm_is_bit_identical_short_k(D, K, last, dtype):
+    """The persistent tile loop on the PRODUCER shapes the test above does not reach: ViT-S (D = 384: proj K = 384 = six K stages,
+    fc2 K = 1536, the last block's fp32 rows; two n-tiles, the second ragged at 128 columns) and the shortest K stream the
+    launcher sends there (K = 256 = four stages: the next tile's stage 0 is requested in the tile's third stage).  Persistent ==
+    one tile per workgroup, bit for bit, run twice."""
+    from mickey_amd import ops
+    dev = _dev()
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    rn = lambda *shape, s=1.0: torch.randn(shape, device=dev, generator=gen) * s  # noqa: E731
+    M = 40 * 1939 if D == 384 else 20 * 1939       # 304 x 2 tiles / 152 x 4 tiles: more tiles than workgroups, ragged last m-tile
+    xf = rn(M, D) * 2 + 0.7
+    hi0 = xf.to(dtype)
+    lo0 = (xf - hi0.float()).to(dtype)
+    a, w = rn(M, K, s=0.5).to(dtype), rn(D, K, s=1 / math.sqrt(K)).to(dtype)
+    b, gamma, shift = rn(D), torch.rand((D,), device=dev, generator=gen), rn(M, s=0.3)
+    ops.gemm_set_tile(7)
+
+    def run(persist):
+        ops.gemm_set_tile(600 if persist else 601)
+        hi, lo = hi0.clone(), lo0.clone()
+        st = torch.full((M, D // 64, 2), float("nan"), device=dev)
+        x_out = torch.zeros((M, D), device=dev) if last else None
+        ops.gemm_ls_residual_ln(a, w, b, gamma, hi, lo, st, x_out=x_out, shift=shift)
+        return [x_out] if last else [hi, lo, st]
+    try:
+        one, per, again = run(False), run(True), run(True)
+        for a_, b_, c_ in zip(one, per, again):
+            assert bool(torch.isfinite(a_.float()).all())
+            assert torch.equal(a_, b_) and torch.equal(b_, c_)
+    finally:
+        ops.gemm_set_tile(600)
+        ops.gemm_set_tile(0)
+
+
 @pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])

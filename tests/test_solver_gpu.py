@@ -240,6 +240,34 @@ def test_sampler_queue_overflow_takes_the_exact_fallback():
     assert abs(chi2 - df) < 5.0 * (2.0 * df) ** 0.5, (chi2, df)
 
 
+def test_sampler_workspace_cleans_itself():
+    """The chain has no zero-fill launch (mickey_hip.h): the state words at the head of the workspace are zero after every call --
+    an ordinary one, one whose pair takes the exact fallback, one with injected noise -- so ONE buffer, zeroed at allocation,
+    serves call after call with the results of a fresh buffer."""
+    from mickey_amd import ops
+    from mickey_amd._native import query
+    dev = _dev()
+    ncell, k, rows, B = 65536, 256, 20, 4
+    gen = torch.Generator().manual_seed(9)
+    benign = (torch.rand((B, ncell), generator=gen) + 0.5) * 1e-5
+    spike = torch.full((ncell,), 1e-7)
+    spike[torch.arange(0, ncell, 16) + 5] = 1.0
+    mixed = benign.clone()
+    mixed[2] = spike
+    noise = -torch.log(torch.rand((B * rows, ncell), generator=gen).clamp_min(1e-12))
+    benign, mixed, noise = benign.to(dev).contiguous(), mixed.to(dev).contiguous(), noise.to(dev)
+    work = ops.exprace_work(B, rows, k, ncell, dev)
+    nstate = query("mk_exprace_topk_state_bytes", B, rows)
+    assert 0 < nstate < work.numel()
+    for it, (pmat, nz) in enumerate(((benign, None), (mixed, None), (benign, noise), (benign, None), (mixed, None))):
+        got = ops.exprace_topk(pmat, rows, k, noise=nz, seed=4, offset=it, work=work)
+        assert int(work[:nstate].count_nonzero()) == 0, it
+        ref = ops.exprace_topk(pmat, rows, k, noise=nz, seed=4, offset=it)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
+    keys = (benign.repeat_interleave(rows, 0) / noise).cpu()
+    _assert_same_sample(ops.exprace_topk(benign, rows, k, noise=noise, work=work)[0], torch.topk(keys, k, dim=1).indices, keys)
+
+
 def test_sampler_overflow_of_one_pair_leaves_the_others_alone():
     """`redo` is per pair: a batch in which ONE pair overflows the skip sampler's queue (the spike matrix of the test above) sends
     that pair through the exact fallback -- and the other pairs' draws are bit-identical to the same pairs in a batch where

@@ -21,8 +21,9 @@ for b in range(B):
 for name, p in (("near-uniform", flat), ("peaked (3000 dominant cells)", peaked)):
     for mode in (0, 1):
         ops.exprace_set_mode(mode)
-        idx, cnt = ops.exprace_topk(p, 20, 2048, seed=1, offset=0)
+        work = ops.exprace_work(B, 20, 2048, n * n, dev)   # zeroed once, self-cleaning afterwards: what the model's workspace holds
+        idx, cnt = ops.exprace_topk(p, 20, 2048, seed=1, offset=0, work=work)
         assert int(cnt.min()) == 2048
-        t = timeit(lambda: ops.exprace_topk(p, 20, 2048, seed=1, offset=3), iters=20, warm=3)
+        t = timeit(lambda: ops.exprace_topk(p, 20, 2048, seed=1, offset=3, work=work), iters=20, warm=3)
         print("B=%d %-30s mode %d (%s): %.3f ms" % (B, name, mode, "skip" if mode == 0 else "pre-filter", t * 1e3), flush=True)
 ops.exprace_set_mode(0)
