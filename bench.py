@@ -368,10 +368,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads-probe", action="store_true", help="CPU leg: also time a small pair at os.cpu_count() threads "
                                                                      "(minutes on a 256-core host)")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--legs", default="ref_split",
+    ap.add_argument("--legs", default="ref_split,natural",
                     help="comma-separated extra legs, each a full timed run written to the detail file: fp16, ref_split, "
-                         "ref_split_fp32mfma, attn_mfma16, vit_small, config5; 'all'; 'none'.  Default: ref_split only (the "
-                         "reference's literal precision split, reported in the line as value_ref_precision)")
+                         "ref_split_fp32mfma, attn_mfma16, vit_small, config5, natural; 'all'; 'none'.  Default: ref_split (the "
+                         "reference's literal precision split, reported in the line as value_ref_precision) and natural (1/f "
+                         "images + massive-activation weights: natural_operands of the line)")
     ap.add_argument("--sustained", action="store_true", help="(default since round 6; kept for old command lines)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 60-step run of the headline configuration ('sustained_60' of the line)")
     ap.add_argument("--precision", action="store_true",
@@ -402,7 +403,7 @@ def parse_args(argv=None):
         args.no_single = args.no_cpu_baseline = True
         args.include_h2d = args.sustained = args.precision = False
         args.legs = "none"
-    all_legs = ("fp16", "ref_split", "ref_split_fp32mfma", "attn_mfma16", "vit_small", "config5")
+    all_legs = ("fp16", "ref_split", "ref_split_fp32mfma", "attn_mfma16", "vit_small", "config5", "natural")
     args.leg_set = set(all_legs) if args.legs == "all" else set() if args.legs in ("none", "") else set(args.legs.split(","))
     unknown = args.leg_set - set(all_legs)
     if unknown:
@@ -640,7 +641,7 @@ def main(argv=None):
 
     sd_cache = {}   # the synthetic checkpoint of an architecture is drawn once (350 M random numbers) and shared by the legs
 
-    def make_model(dtype, heads=None, arch="vit_large", matcher=None):
+    def make_model(dtype, heads=None, arch="vit_large", matcher=None, outliers=False):
         cfg = default_cfg()
         cfg["AMD"]["ENCODER_DTYPE"] = dtype
         cfg["AMD"]["HEADS_DTYPE"] = heads or args.heads_dtype
@@ -651,9 +652,14 @@ def main(argv=None):
         cfg["MICKEY"]["DINOV2"]["CHANNEL_DIM"] = syn.VIT_ARCH[arch][0]
         if matcher:
             cfg["FEATURE_MATCHER"]["TYPE"] = matcher
-        key = (arch, cfg["FEATURE_MATCHER"]["TYPE"])
+        key = (arch, cfg["FEATURE_MATCHER"]["TYPE"], bool(outliers))
         if key not in sd_cache:
-            sd_cache[key] = syn.mickey_state_dict(cfg, seed=0, arch=arch)
+            plain = sd_cache.get(key[:2] + (False,))
+            if outliers and plain is not None:   # the same draw as mickey_state_dict(outliers=True): a copy with the outliers planted
+                sd_cache[key] = {k: v.clone() for k, v in plain.items()}
+                syn.plant_outliers(sd_cache[key], arch, syn.DINO_PREFIX, 0)
+            else:
+                sd_cache[key] = syn.mickey_state_dict(cfg, seed=0, arch=arch, outliers=bool(outliers))
         sd = sd_cache[key]
         m = MickeyRelativePose(cfg)
         m.load_state_dict(sd)
@@ -699,6 +705,18 @@ def main(argv=None):
         if prof is not None and prof.records:
             stages, by = prof.summary(ev_steps)
             roof = roofline_entry(stages, by, B, args.dtype, model)
+            if roof is not None:
+                # what the socket power limit lets through the matrix pipe ALONE on this box right now (register-resident
+                # pseudo-random bf16 operands, no memory traffic; mickey_hip_dev.h, LABNOTES R4.11): the ceiling of the MFMA
+                # instruction itself next to the 2.5 PFLOP/s spec that `frac` is quoted against.  Never `peak`.
+                try:
+                    ps = ops.dev_mfma_sustained(dev)
+                    roof["peak_sustained"], roof["frac_sustained"] = ps, roof["achieved"] / ps
+                    roof["peak_sustained_note"] = ("back-to-back v_mfma_f32_16x16x32_bf16 on register-resident pseudo-random operands, "
+                                                   "all CUs x 8 waves, one ~100-ms launch straight after the timed region "
+                                                   "(mk_dev_mfma_sustained); zeros as operands: %.0f" % ops.dev_mfma_sustained(dev, zero_operands=True))
+                except Exception as e:   # a probe must not cost the line
+                    roof["peak_sustained_note"] = "probe failed: %s: %s" % (type(e).__name__, str(e)[:200])
             if roof is not None and graphed:
                 roof["note"] = (roof.get("note", "") + "; forward replayed as a hipGraph in the timed region; kernel events "
                                 "from one extra eager step").lstrip("; ")
@@ -764,10 +782,14 @@ def main(argv=None):
     def _leg(name, what, dtype, steps, warmup, batch_pairs, hw, dominant, **mk):
         bp = batch_pairs or B
         attn_mode = mk.pop("attn_mode", None)   # dev knob (process-wide): set for this leg only
+        natural = mk.pop("natural", False)      # 1/f-spectrum images generated on the device instead of white noise
         if attn_mode is not None:
             ops.attn_set_mode(attn_mode)
         m, _, _ = make_model(dtype, **mk)
-        d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=bp, H=hw[0], W=hw[1], seed=1234).items()}
+        if natural:
+            d = syn.natural_batch(B=bp, H=hw[0], W=hw[1], seed=1234, device=dev)
+        else:
+            d = {k: v.to(dev) for k, v in syn.synthetic_batch(B=bp, H=hw[0], W=hw[1], seed=1234).items()}
         a = argparse.Namespace(**vars(args))
         a.steps, a.warmup = steps, warmup
         if prof is not None:
@@ -806,6 +828,12 @@ def main(argv=None):
     leg("config5", "BASELINE.json configs[4]: 8 pairs of 1280x720 (51x91 grid, n = 4641), Sinkhorn matcher (10 "
         "iterations; governed by HBM: 20 LSE passes over the (n+1)^2 fp32 coupling matrix = 301 MB per pair at 540x720, "
         "1.72 GB here), fp16 operands", "fp16", 3, 1, batch_pairs=8, hw=(720, 1280), dominant="matcher", matcher="Sinkhorn")
+
+    leg("natural", "REALISTIC OPERANDS (never `value`): the headline configuration on images with a 1/f amplitude spectrum "
+        "(synthetic.natural_batch, drawn and filtered on the device) and encoder weights with the massive-activation statistics of "
+        "released ViT-L weights (synthetic.plant_outliers: 4 residual channels at |x| ~ 600, compensating LayerNorm gains, hot "
+        "attention heads) -- what the socket power limit lets through when the operand bits are not uniform noise (LABNOTES R4.11)",
+        args.dtype, args.steps, args.warmup, outliers=True, natural=True)
 
     if rank == 0:
         tick("legs measured")
@@ -851,7 +879,8 @@ def compact_line(out, detail_path=None):
     roof = out.get("roofline")
     if roof:
         line["roofline"] = {k: r4(roof.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                         "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "traffic_source")}
+                                                         "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "traffic_source",
+                                                         "peak_sustained", "frac_sustained") if k in roof or not k.endswith("sustained")}
         st = sorted(roof.get("stages") or [], key=lambda s: -s["ms_per_step"])[:6]
         line["stages"] = [{"stage": s["stage"], "ms_per_step": r4(s["ms_per_step"]), "frac": r4(s.get("frac"))} for s in st]
     else:
@@ -865,6 +894,9 @@ def compact_line(out, detail_path=None):
     if "value" in rs:
         line["value_ref_precision"] = r4(rs["value"])
         line["ref_precision"] = "fp16 ViT + fp32-grade heads (the reference's split, mickey_extractor.py:49-56)"
+    nat = (out.get("legs") or {}).get("natural") or {}
+    if "value" in nat:   # realistic operand statistics (1/f images, massive-activation weights): information, never `value`
+        line["natural_operands"] = {"value": r4(nat["value"]), "encoder_gemm_tflops": r4((nat.get("roofline") or {}).get("achieved"))}
     sp = out.get("single_pair") or {}
     if "ms_per_pair" in sp:
         line["single_pair_ms"] = r4(sp["ms_per_pair"])
@@ -877,7 +909,7 @@ def compact_line(out, detail_path=None):
     txt = json.dumps(line, separators=(",", ":"))
     # cannot happen with the keys above; if it ever does, optional keys go first and free-text fields are cut -- the line is
     # printed whatever happens (an oversized or missing line is an unmeasured round)
-    for k in ("ref_precision", "detail", "stages", "single_pair_ms", "per_rank_ms_per_step", "sustained_60"):
+    for k in ("ref_precision", "detail", "natural_operands", "stages", "single_pair_ms", "per_rank_ms_per_step", "sustained_60"):
         if len(txt) < LINE_LIMIT:
             break
         line.pop(k, None)

@@ -76,6 +76,7 @@ DEV_SIGNATURES = {
     "mk_sinkhorn_set_group": ("i", "i"),
     "mk_dual_softmax_set_chunks": ("i", "i"),
     "mk_exprace_set_mode": ("i", "i"),
+    "mk_dev_mfma_sustained": ("i", "piiip"),
 }
 
 _lib = None

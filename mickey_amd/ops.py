@@ -392,6 +392,20 @@ def exprace_set_mode(mode):
     call("mk_exprace_set_mode", int(mode))
 
 
+def dev_mfma_sustained(device, iters=400000, zero_operands=False, workgroups=None):
+    """Measurement probe (mickey_hip_dev.h: mk_dev_mfma_sustained): TFLOP/s of back-to-back v_mfma_f32_16x16x32 (bf16) on
+    register-resident operands, one 8-wave workgroup per CU, one warm launch + one timed launch (HIP events).  Not product code."""
+    wg = workgroups or torch.cuda.get_device_properties(device).multi_processor_count
+    scratch = torch.empty((wg * 512,), device=device, dtype=torch.float32)
+    call("mk_dev_mfma_sustained", ptr(scratch), wg, max(1, iters // 8), int(zero_operands), stream())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call("mk_dev_mfma_sustained", ptr(scratch), wg, iters, int(zero_operands), stream())
+    e1.record()
+    e1.synchronize()
+    return wg * iters * 1048576.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def exprace_work(B, rows_per_pair, k, ncell, device):
     """Workspace of mk_exprace_topk with its self-cleaning state zeroed (mickey_hip.h): allocate ONCE per shape and stream and
     hand it to every exprace_topk call -- a call leaves the state zero, so no zero-fill launch stands in front of the chain."""

@@ -220,6 +220,34 @@ def synthetic_batch(B=1, H=720, W=540, seed=1234):
     }
 
 
+def natural_batch(B=1, H=720, W=540, seed=1234, device=None):
+    """synthetic_batch() with images that have a photograph's statistics instead of white noise: Gaussian noise shaped to a 1/f
+    amplitude spectrum per channel (a shared luminance field + 30 % of an independent field per colour channel), each image
+    rescaled to mean 0.45 / std 0.22 and clamped to [0, 1].  Neighbouring pixels are correlated (the patch embedding sees
+    smooth patches, not 588 independent uniforms); used by bench.py's `natural` leg, never by the headline.  device: where
+    the fields are drawn and filtered (input generation, not part of any forward)."""
+    device = torch.device(device or "cpu")
+
+    def field(g, n):
+        x = torch.randn((n, H, W), generator=g, device=device)
+        fy = torch.fft.fftfreq(H, device=device).view(H, 1)
+        fx = torch.fft.rfftfreq(W, device=device).view(1, W // 2 + 1)
+        amp = 1.0 / torch.sqrt(fy * fy + fx * fx).clamp_min(1.0 / max(H, W))
+        amp[0, 0] = 0.0
+        y = torch.fft.irfft2(torch.fft.rfft2(x) * amp, s=(H, W))
+        return y / y.flatten(1).std(1).view(n, 1, 1)
+
+    out = synthetic_batch(B, 8, 8, seed)   # the intrinsics
+    for key, sd in (("image0", seed), ("image1", seed + 1)):
+        g = torch.Generator(device=device).manual_seed(sd + 77)
+        lum = field(g, B).view(B, 1, H, W)
+        col = field(g, 3 * B).view(B, 3, H, W)
+        img = lum + 0.3 * col
+        img = img / img.flatten(1).std(1).view(B, 1, 1, 1)
+        out[key] = (0.45 + 0.22 * img).clamp_(0.0, 1.0).contiguous()
+    return {k: v.to(device) for k, v in out.items()}
+
+
 def planted_pose_problem(B=1, h=51, w=38, seed=4321, inlier_frac=0.6, down=14, angle_deg=(5.0, 10.0),
                          t_norm=(0.3, 0.4)):
     """Solver-realism generator: a known relative pose is planted into
