@@ -131,9 +131,10 @@ def test_stub_line_is_last_and_small():
 
 
 def test_default_arguments_keep_the_driver_run_short():
-    """The default run = headline + 60 sustained steps + ref_split leg + one-pair leg + CPU baseline; everything else is opt-in."""
+    """The default run = headline + 60 sustained steps + ref_split and natural-operands legs + one-pair leg + CPU baseline (59 s on
+    the box, profiles/r06i_*); everything else is opt-in."""
     a = bench.parse_args([])
-    assert a.leg_set == {"ref_split"} and a.sustained and not a.include_h2d and not a.precision
+    assert a.leg_set == {"ref_split", "natural"} and a.sustained and not a.include_h2d and not a.precision
     assert not bench.parse_args(["--no-sustained"]).sustained
     assert bench.parse_args(["--legs", "all"]).leg_set >= {"fp16", "ref_split", "vit_small", "config5"}
     lean = bench.parse_args(["--lean"])
