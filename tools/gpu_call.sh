@@ -15,6 +15,7 @@ for step in "$@"; do
     matcher) timeout 300 python tools/bench_matcher.py dual 2>&1 | tail -12 | tee gpurun_out/${TAG}_bench_matcher.txt ;;
     sampler) timeout 300 python tools/bench_sampler.py 2>&1 | tail -12 | tee gpurun_out/${TAG}_bench_sampler.txt ;;
     gemm)    timeout 600 python tools/bench_gemm.py $arg 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_vs_hipblaslt.txt ;;
+    gemmb1)  timeout 600 python tools/bench_gemm_b1.py 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_b1.txt ;;
     persist) timeout 600 python tools/bench_persist.py 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_persistent.txt ;;
     lnfold)  timeout 600 python tools/bench_lnfold.py 2>&1 | tail -6 | tee gpurun_out/${TAG}_bench_lnfold.txt ;;
     attn)    timeout 300 python tools/bench_attn.py $arg 2>&1 | tail -4 | tee gpurun_out/${TAG}_bench_attn.txt ;;
