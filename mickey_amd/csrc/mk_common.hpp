@@ -50,6 +50,8 @@ __device__ __forceinline__ float sat16(float sv, int* flag) {
   return sv != sv ? sv : c;
 }
 
+namespace gemm { int num_cus(); }   // CUs of the current device (mk_gemm.hip; cached)
+
 // ---- MFMA wrappers: 16-bit operand type selects the instruction ---------------------------------
 template <typename T> struct Lp;  // low-precision operand traits
 template <> struct Lp<__bf16> {

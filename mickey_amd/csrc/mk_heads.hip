@@ -160,23 +160,50 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 
 // ---- tails ---------------------------------------------------------------------------------------
 
-// detector: one workgroup per image (reference mickey_extractor.py:98-124,134-138)
-__global__ __launch_bounds__(1024) void det_tail_kernel(const float* __restrict__ feat, const float* __restrict__ wsc,
-                                                        float* __restrict__ scr, int h, int w, int C, int border,
-                                                        int use_softmax) {
+// detector logits + offset + depth: one wave per pixel, three C-long dot products from the three kp heads' features
+// (reference mickey_extractor.py:134-138,172-178,213-218).  The raw detector logit goes to scr, which det_norm_kernel
+// then normalises in place (round 6: the logits used to be computed by the one-workgroup-per-image normaliser itself, 121
+// dependent row reads per wave = 67 us for ANY batch size)
+__global__ __launch_bounds__(256) void kp_depth_tail_kernel(const float* __restrict__ fdet, const float* __restrict__ wsc,
+                                                            const float* __restrict__ foff, const float* __restrict__ wxy,
+                                                            const float* __restrict__ fdep, const float* __restrict__ wd,
+                                                            float* __restrict__ scr, float* __restrict__ kps,
+                                                            float* __restrict__ depth, int nimg, int h, int w, int C,
+                                                            int use_depth_sigmoid, float max_depth, float down) {
+  const int n = h * w;
+  const long long gp = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (gp >= (long long)nimg * n) return;
+  const int lane = threadIdx.x & 63;
+  const int img = (int)(gp / n), p = (int)(gp % n);
+  float as = 0.f, ax = 0.f, ay = 0.f, ad = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float fo = foff[gp * C + c];
+    as += fdet[gp * C + c] * wsc[c];
+    ax += fo * wxy[c];
+    ay += fo * wxy[C + c];
+    ad += fdep[gp * C + c] * wd[c];
+  }
+  as = wave_sum(as);
+  ax = wave_sum(ax);
+  ay = wave_sum(ay);
+  ad = wave_sum(ad);
+  if (lane == 0) {
+    const int y = p / w, x = p % w;
+    scr[gp] = as;
+    kps[((long long)img * 2 + 0) * n + p] = (1.0f / (1.0f + expf(-ax)) + (float)x) * down;
+    kps[((long long)img * 2 + 1) * n + p] = (1.0f / (1.0f + expf(-ay)) + (float)y) * down;
+    depth[gp] = use_depth_sigmoid ? max_depth * (1.0f / (1.0f + expf(-ad))) : ad;
+  }
+}
+
+// detector: the logits of one image (in scr) -> scores, in place; one workgroup per image (reference mickey_extractor.py:98-124)
+__global__ __launch_bounds__(1024) void det_norm_kernel(float* __restrict__ scr, int h, int w, int border, int use_softmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [n] scores + [32] reduction scratch
   const int n = h * w;
   float* sred = sm + n;
   const int img = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  // one wave per pixel: C-long dot product
-  for (int p = wave; p < n; p += nw) {
-    const float* f = feat + ((long long)img * n + p) * C;
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += f[c] * wsc[c];
-    a = wave_sum(a);
-    if (lane == 0) sm[p] = a;
-  }
+  for (int p = threadIdx.x; p < n; p += blockDim.x) sm[p] = scr[(long long)img * n + p];
   __syncthreads();
   if (!use_softmax) {
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
@@ -210,35 +237,6 @@ __global__ __launch_bounds__(1024) void det_tail_kernel(const float* __restrict_
   for (int i = 0; i < nw; ++i) sum += sred[i];
   const float inv = 1.0f / (sum + 1e-16f);
   for (int p = threadIdx.x; p < n; p += blockDim.x) scr[(long long)img * n + p] = sm[p] * inv;
-}
-
-// offset + depth: one wave per pixel
-__global__ __launch_bounds__(256) void kp_depth_tail_kernel(const float* __restrict__ foff, const float* __restrict__ wxy,
-                                                            const float* __restrict__ fdep, const float* __restrict__ wd,
-                                                            float* __restrict__ kps, float* __restrict__ depth, int nimg,
-                                                            int h, int w, int C, int use_depth_sigmoid, float max_depth,
-                                                            float down) {
-  const int n = h * w;
-  const long long gp = blockIdx.x * 4LL + (threadIdx.x >> 6);
-  if (gp >= (long long)nimg * n) return;
-  const int lane = threadIdx.x & 63;
-  const int img = (int)(gp / n), p = (int)(gp % n);
-  float ax = 0.f, ay = 0.f, ad = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float fo = foff[gp * C + c];
-    ax += fo * wxy[c];
-    ay += fo * wxy[C + c];
-    ad += fdep[gp * C + c] * wd[c];
-  }
-  ax = wave_sum(ax);
-  ay = wave_sum(ay);
-  ad = wave_sum(ad);
-  if (lane == 0) {
-    const int y = p / w, x = p % w;
-    kps[((long long)img * 2 + 0) * n + p] = (1.0f / (1.0f + expf(-ax)) + (float)x) * down;
-    kps[((long long)img * 2 + 1) * n + p] = (1.0f / (1.0f + expf(-ay)) + (float)y) * down;
-    depth[gp] = use_depth_sigmoid ? max_depth * (1.0f / (1.0f + expf(-ad))) : ad;
-  }
 }
 
 // descriptors: l2-normalise over channels and transpose [pix, Cd] -> [Cd, pix]; block = 64 pixels
@@ -338,11 +336,10 @@ int mk_head_tails(const float* feat_det, const float* w_score, const float* feat
   MK_CHECK_ARG(nimg > 0 && n > 0 && C > 0 && Cd > 0 && (size_t)(n + 32) * 4 <= 160 * 1024 && Cd * 65 * 4 <= 160 * 1024,
                "mk_head_tails: bad geometry");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(det_tail_kernel, dim3(nimg), dim3(1024), (size_t)(n + 32) * sizeof(float), st, feat_det, w_score, scr, h,
-                     w, C, border, use_softmax);
+  hipLaunchKernelGGL(kp_depth_tail_kernel, dim3((unsigned)(((long long)nimg * n + 3) / 4)), dim3(256), 0, st, feat_det, w_score,
+                     feat_off, w_xy, feat_depth, w_depth, scr, kps, depth, nimg, h, w, C, use_depth_sigmoid, max_depth, down);
   MK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(kp_depth_tail_kernel, dim3((unsigned)(((long long)nimg * n + 3) / 4)), dim3(256), 0, st, feat_off, w_xy,
-                     feat_depth, w_depth, kps, depth, nimg, h, w, C, use_depth_sigmoid, max_depth, down);
+  hipLaunchKernelGGL(det_norm_kernel, dim3(nimg), dim3(1024), (size_t)(n + 32) * sizeof(float), st, scr, h, w, border, use_softmax);
   MK_CHECK_LAUNCH();
   hipLaunchKernelGGL(dsc_tail_kernel, dim3((n + 63) / 64, nimg), dim3(256), (size_t)Cd * 65 * sizeof(float), st, feat_dsc, dsc,
                      n, Cd, norm_dsc);

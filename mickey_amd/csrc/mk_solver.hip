@@ -1597,7 +1597,11 @@ int mk_ransac_hypotheses(const float* X, const float* Y, const float* wts, const
                          mk_stream_t stream) {
   MK_CHECK_ARG(X && Y && wts && Rh && th && score && idx3, "mk_ransac_hypotheses: null pointer");
   MK_CHECK_ARG(nsets > 0 && it_ransac > 0 && k >= 3 && (size_t)k * 32 + 1024 <= 150 * 1024, "mk_ransac_hypotheses: bad sizes (k <= 4768)");
-  const int nsplit = it_ransac >= 16 ? 4 : 1;
+  // blocks per correspondence set: 4 (25 hypotheses per block, 6 - 7 per wave) when the sets alone fill the part; with few sets
+  // (one pair: 20) as many as keep every wave at >= one hypothesis and the launch at ~2 blocks per CU -- a hypothesis' arithmetic and
+  // draws do not depend on the block it is computed in (keyed by its global index): bit-identical for any split
+  int nsplit = it_ransac >= 16 ? 4 : 1;
+  if (it_ransac >= 16) nsplit = max(4, min((it_ransac + 3) / 4, (2 * mk::gemm::num_cus() + nsets - 1) / nsets));
   const size_t lds = ((size_t)k * 8 + 256) * sizeof(float);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)hypotheses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
