@@ -346,6 +346,14 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
                           const float* kps1, const float* depth1, const float* K0, const float* K1, float* X, float* Y,
                           float* wts, float* corr, int B, int rows_per_pair, int k, int n0, int n1, mk_stream_t stream);
 
+/* Backward of mk_gather_backproject w.r.t. keypoints and depths (training: loss_class.py:139-146 + training_utils.py:7-22 under
+ * autograd; intrinsics and scores get no gradient).  gX, gY [B*rows_per_pair, k, 3] = dL/dX, dL/dY; corr as written by the forward;
+ * gkps [B, 2, n], gdepth [B, n] must be ZEROED by the caller: contributions are accumulated with fp32 atomic adds (a keypoint is
+ * drawn by many cells; the order of the additions is not fixed, as in torch's index backward). */
+int mk_gather_backproject_bwd(const int* idx, const float* corr, const float* gX, const float* gY, const float* K0, const float* K1,
+                              float* gkps0, float* gdepth0, float* gkps1, float* gdepth1, int B, int rows_per_pair, int k, int n0,
+                              int n1, mk_stream_t stream);
+
 /* Hypothesis generation and scoring (probabilisticProcrustes.py:247-268; loss/solvers.py:31-52;
  * training_utils.py:55-61).  For every correspondence set r (k points) and every h in [0, it_ransac):
  * draw 3 of k without replacement weighted by wts (exponential race; noise3 = NULL: Philox, else fp32
@@ -413,6 +421,23 @@ int mk_train_tail_bwd(const float* X, const float* Y, const float* mask, const f
                       const float* K1, int nsets, int it_ransac, int S, int it_matches, float th_soft, int loss_type,
                       int soft_clip, float img_h, const float* Rt, const float* saved, const float* grad_out, float* work,
                       float* gX, float* gY, mk_stream_t stream);
+
+/* The reductions between the tail and the loss (loss_class.py:229-246, :263-268), forward and backward:
+ *   forward   per set (row = b*it_matches + o) of it_ransac hypotheses, from out [nhyp, 4] of mk_train_tail_fwd:
+ *               sm      = softmax over [score_k / temperature (, null_score / temperature if add_null)]
+ *               loss_value[row] = sum_k sm_k loss_k (+ sm_null * null_loss)                                   (:240-246)
+ *               rot / trans     = sum_k softmax(score / temperature)_k (rot_k | trans_k), WITHOUT the null column     (:229-238)
+ *               coef [nhyp, 2]  = d loss_value[row] / d (loss_k, score_k) = (sm_k, sm_k (loss_k - loss_value[row]) / temperature)
+ *             per pair: per_pair [B, 3] = sums over its it_matches rows of (loss_value, rot, trans), in row order        (:263-268)
+ *             flags int32 [2] (caller zeroes): [0] |= 1 if any R / t of Rt [nhyp, 12] is not finite (:225-227), [1] += number of
+ *             hypotheses whose cross-covariance has rank one (singular values saved[:, 18:21]; torch.linalg.matrix_rank, :190).
+ *   backward  grad_out [nhyp, 2] = g_pair[b] * coef  (g_pair [B] = dL/d per_pair[:, 0]; what mk_train_tail_bwd takes)
+ * it_matches <= 64. */
+int mk_train_aggregate_fwd(const float* out, const float* Rt, const float* saved, int B, int it_matches, int it_ransac,
+                           float temperature, int add_null, float null_loss, float null_score, float* loss_value, float* per_pair,
+                           float* coef, int* flags, mk_stream_t stream);
+int mk_train_aggregate_bwd(const float* coef, const float* g_pair, int B, int it_matches, int it_ransac, float* grad_out,
+                           mk_stream_t stream);
 
 /* REINFORCE bookkeeping of the same function (loss_class.py:251-261, a python loop over B*it_matches rows in the
  * reference): for row = b*it_matches + r, r ascending, and every sampled cell c = idx[row, s]:

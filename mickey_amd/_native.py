@@ -59,6 +59,7 @@ SIGNATURES = {
     "mk_exprace_topk": ("i", "ppuupppppiiliip"),
     "mk_counter_add": ("i", "pup"),
     "mk_gather_backproject": ("i", "ppppppppppppiiiiip"),
+    "mk_gather_backproject_bwd": ("i", "ppppppppppiiiiip"),
     "mk_ransac_hypotheses": ("i", "pppppuupfppppiiilp"),
     "mk_refine_pose": ("i", "pppppfiipppppppiiiip"),
     "mk_pose_finalize": ("i", "ppppip"),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "mk_reinforce_scatter": ("i", "ppppiiilp"),
     "mk_train_tail_fwd": ("i", "pppppppiiiifiifpppp"),
     "mk_train_tail_bwd": ("i", "pppppppiiiifiifppppppp"),
+    "mk_train_aggregate_fwd": ("i", "pppiiififfppppp"),
+    "mk_train_aggregate_bwd": ("i", "ppiiipp"),
 }
 
 # development knobs (include/mickey_hip_dev.h): process-wide schedule selectors for benchmarks / tests, never called by

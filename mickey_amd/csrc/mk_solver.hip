@@ -885,6 +885,46 @@ __global__ __launch_bounds__(256) void gather_backproject_kernel(const int* __re
   cr[0] = u0; cr[1] = v0; cr[2] = u1; cr[3] = v1; cr[4] = d0; cr[5] = d1;
 }
 
+// Backward of the above w.r.t. the keypoints and depths (training: reference loss_class.py:139-146 under autograd; the
+// intrinsics are detached).  X_a = d (Ki[a,0] u + Ki[a,1] v + Ki[a,2]):  dL/du = d sum_a gX_a Ki[a,0], dL/dv = d sum_a gX_a Ki[a,1],
+// dL/dd = sum_a gX_a (Ki[a,:] . [u, v, 1]).  A keypoint is drawn by many cells of many rows: fp32 atomic adds into zeroed
+// outputs (what torch's index backward does on a GPU too).
+__global__ __launch_bounds__(256) void gather_backproject_bwd_kernel(const int* __restrict__ idx, const float* __restrict__ corr,
+                                                                     const float* __restrict__ gX, const float* __restrict__ gY,
+                                                                     const float* __restrict__ K0, const float* __restrict__ K1,
+                                                                     float* __restrict__ gkps0, float* __restrict__ gdep0,
+                                                                     float* __restrict__ gkps1, float* __restrict__ gdep1,
+                                                                     int rows_per_pair, int k, int n0, int n1) {
+  const int r = blockIdx.y, b = r / rows_per_pair;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= k) return;
+  float Ki0[9], Ki1[9];
+  inv3(K0 + b * 9, Ki0);
+  inv3(K1 + b * 9, Ki1);
+  const long long o = (long long)r * k + s;
+  const int c = idx[o];
+  const int i = c / n1, j = c - i * n1;
+  const float* cr = corr + o * 6;
+  const float u0 = cr[0], v0 = cr[1], u1 = cr[2], v1 = cr[3], d0 = cr[4], d1 = cr[5];
+  float gu0 = 0.f, gv0 = 0.f, gd0 = 0.f, gu1 = 0.f, gv1 = 0.f, gd1 = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float gx = gX[o * 3 + a], gy = gY[o * 3 + a];
+    gu0 += gx * Ki0[a * 3 + 0];
+    gv0 += gx * Ki0[a * 3 + 1];
+    gd0 += gx * (Ki0[a * 3 + 0] * u0 + Ki0[a * 3 + 1] * v0 + Ki0[a * 3 + 2]);
+    gu1 += gy * Ki1[a * 3 + 0];
+    gv1 += gy * Ki1[a * 3 + 1];
+    gd1 += gy * (Ki1[a * 3 + 0] * u1 + Ki1[a * 3 + 1] * v1 + Ki1[a * 3 + 2]);
+  }
+  atomicAdd(gkps0 + ((long long)b * 2 + 0) * n0 + i, d0 * gu0);
+  atomicAdd(gkps0 + ((long long)b * 2 + 1) * n0 + i, d0 * gv0);
+  atomicAdd(gdep0 + (long long)b * n0 + i, gd0);
+  atomicAdd(gkps1 + ((long long)b * 2 + 0) * n1 + j, d1 * gu1);
+  atomicAdd(gkps1 + ((long long)b * 2 + 1) * n1 + j, d1 * gv1);
+  atomicAdd(gdep1 + (long long)b * n1 + j, gd1);
+}
+
 // ---- 3x3 Kabsch: R = V diag(1,1,det(V U^T)) U^T for H = U S V^T (reference loss/solvers.py:45-50) ----
 // One-sided Jacobi on the columns of H (no H^T H: keeps fp32-level relative accuracy of the small
 // singular directions), fp64, then the two leading singular pairs + right-handed completion, which
@@ -1587,6 +1627,17 @@ int mk_gather_backproject(const int* idx, const float* final_scores, const float
   MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && k > 0 && n0 > 0 && n1 > 0, "mk_gather_backproject: bad sizes");
   hipLaunchKernelGGL(gather_backproject_kernel, dim3((k + 255) / 256, B * rows_per_pair), dim3(256), 0, (hipStream_t)stream, idx,
                      final_scores, kps0, depth0, kps1, depth1, K0, K1, X, Y, wts, corr, rows_per_pair, k, n0, n1);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_gather_backproject_bwd(const int* idx, const float* corr, const float* gX, const float* gY, const float* K0, const float* K1,
+                              float* gkps0, float* gdepth0, float* gkps1, float* gdepth1, int B, int rows_per_pair, int k, int n0,
+                              int n1, mk_stream_t stream) {
+  MK_CHECK_ARG(idx && corr && gX && gY && K0 && K1 && gkps0 && gdepth0 && gkps1 && gdepth1, "mk_gather_backproject_bwd: null pointer");
+  MK_CHECK_ARG(B > 0 && rows_per_pair > 0 && k > 0 && n0 > 0 && n1 > 0, "mk_gather_backproject_bwd: bad sizes");
+  hipLaunchKernelGGL(gather_backproject_bwd_kernel, dim3((k + 255) / 256, B * rows_per_pair), dim3(256), 0, (hipStream_t)stream, idx,
+                     corr, gX, gY, K0, K1, gkps0, gdepth0, gkps1, gdepth1, rows_per_pair, k, n0, n1);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -521,7 +521,97 @@ int fill(TailParams& p, const float* X, const float* Y, const float* mask, const
 
 }  // namespace
 
+// ---- aggregation: hypotheses of a set -> the set's loss, sets of a pair -> the pair's baseline ---------------------------------
+// reference loss_class.py:229-246 (softmax of the scores / temperature over the it_ransac hypotheses of a set, with the null
+// hypothesis as one more column; rotation / translation errors under the softmax WITHOUT that column) and :263-268 (sums over the
+// it_matches sets of a pair).  One workgroup per pair, one wave per set (lanes = hypotheses), the pair's sums in set order.
+// coef [nhyp, 2] = d loss_value(set) / d (loss_k, score_k): the backward is g(pair) * coef.
+__global__ __launch_bounds__(256) void train_aggregate_fwd_kernel(const float* __restrict__ out, const float* __restrict__ Rt,
+                                                                  const float* __restrict__ saved, int it_r, int it_m, float temp,
+                                                                  int add_null, float null_loss, float null_score,
+                                                                  float* __restrict__ loss_value, float* __restrict__ per_pair,
+                                                                  float* __restrict__ coef, int* __restrict__ flags) {
+  __shared__ float srow[3][64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bad = 0, rank1 = 0;
+  for (int o = wave; o < it_m; o += 4) {
+    const long long row = (long long)b * it_m + o;
+    float vmax = add_null ? null_score / temp : -INFINITY;
+    for (int h = lane; h < it_r; h += 64) vmax = fmaxf(vmax, out[(row * it_r + h) * 4 + 3] / temp);
+    vmax = wave_max(vmax);
+    float z = 0.f, zl = 0.f, zr = 0.f, zt = 0.f;
+    for (int h = lane; h < it_r; h += 64) {
+      const float* q = out + (row * it_r + h) * 4;
+      const float e = expf(q[3] / temp - vmax);
+      z += e; zl += e * q[0]; zr += e * q[1]; zt += e * q[2];
+      const float* rt = Rt + (row * it_r + h) * 12;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) bad |= !(fabsf(rt[i]) <= 3.0e38f);   // NaN or inf
+      const float* sv = saved + (row * it_r + h) * 32 + 18;               // singular values of H: rank one = exactly one above max * 3 eps
+      const float smax = fmaxf(sv[0], fmaxf(sv[1], sv[2])), tol = smax * 3.f * 1.1920929e-07f;
+      rank1 += ((sv[0] > tol) + (sv[1] > tol) + (sv[2] > tol)) == 1;
+    }
+    z = wave_sum(z); zl = wave_sum(zl); zr = wave_sum(zr); zt = wave_sum(zt);
+    const float en = add_null ? expf(null_score / temp - vmax) : 0.f;
+    const float Z = z + en;
+    const float lv = (zl + en * null_loss) / Z;
+    for (int h = lane; h < it_r; h += 64) {
+      const float* q = out + (row * it_r + h) * 4;
+      const float sm = expf(q[3] / temp - vmax) / Z;
+      coef[(row * it_r + h) * 2 + 0] = sm;
+      coef[(row * it_r + h) * 2 + 1] = sm * (q[0] - lv) / temp;
+    }
+    if (lane == 0) {
+      loss_value[row] = lv;
+      srow[0][o & 63] = lv; srow[1][o & 63] = zr / z; srow[2][o & 63] = zt / z;
+    }
+  }
+  bad = __any(bad);
+  rank1 = (int)wave_sum((float)rank1);
+  if (lane == 0) {
+    if (bad) atomicOr(flags + 0, 1);
+    if (rank1) atomicAdd(flags + 1, rank1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float a = 0.f;
+    for (int o = 0; o < it_m; ++o) a += srow[threadIdx.x][o];
+    per_pair[b * 3 + threadIdx.x] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void train_aggregate_bwd_kernel(const float* __restrict__ coef, const float* __restrict__ g_pair,
+                                                                  int per_pair_hyp, long long nhyp, float* __restrict__ g) {
+  const long long h = blockIdx.x * 256LL + threadIdx.x;
+  if (h >= nhyp) return;
+  const float gp = g_pair[h / per_pair_hyp];
+  g[h * 2 + 0] = gp * coef[h * 2 + 0];
+  g[h * 2 + 1] = gp * coef[h * 2 + 1];
+}
+
 extern "C" {
+
+int mk_train_aggregate_fwd(const float* out, const float* Rt, const float* saved, int B, int it_matches, int it_ransac,
+                           float temperature, int add_null, float null_loss, float null_score, float* loss_value, float* per_pair,
+                           float* coef, int* flags, mk_stream_t stream) {
+  MK_CHECK_ARG(out && Rt && saved && loss_value && per_pair && coef && flags, "mk_train_aggregate_fwd: null pointer");
+  MK_CHECK_ARG(B > 0 && it_matches > 0 && it_matches <= 64 && it_ransac > 0 && temperature > 0.f,
+               "mk_train_aggregate_fwd: bad sizes (it_matches <= 64)");
+  hipLaunchKernelGGL(train_aggregate_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, Rt, saved, it_ransac, it_matches,
+                     temperature, add_null, null_loss, null_score, loss_value, per_pair, coef, flags);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_train_aggregate_bwd(const float* coef, const float* g_pair, int B, int it_matches, int it_ransac, float* grad_out,
+                           mk_stream_t stream) {
+  MK_CHECK_ARG(coef && g_pair && grad_out && B > 0 && it_matches > 0 && it_ransac > 0, "mk_train_aggregate_bwd: bad args");
+  const long long nh = (long long)B * it_matches * it_ransac;
+  hipLaunchKernelGGL(train_aggregate_bwd_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coef, g_pair,
+                     it_matches * it_ransac, nh, grad_out);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
 
 int mk_train_tail_fwd(const float* X, const float* Y, const float* mask, const float* Rgt, const float* tgt, const float* K0,
                       const float* K1, int nsets, int it_ransac, int S, int it_matches, float th_soft, int loss_type,

@@ -523,6 +523,41 @@ def train_tail_bwd(X, Y, mask, Rgt, tgt, K0, K1, it_ransac, it_matches, th_soft,
     return gX, gY
 
 
+def train_aggregate_fwd(out, Rt, saved, B, it_matches, it_ransac, temperature, add_null, null_loss, null_score):
+    """mk_train_aggregate_fwd: -> (loss_value [B*it_matches], per_pair [B, 3] = sums of (loss_value, rot, trans) over a pair's sets,
+    coef [nhyp, 2] for the backward, flags int32 [2] = (any non-finite R / t, number of rank-one hypotheses))."""
+    out, Rt, saved = _c(out, Rt, saved)
+    dev = out.device
+    loss_value = torch.empty((B * it_matches,), device=dev, dtype=torch.float32)
+    per_pair = torch.empty((B, 3), device=dev, dtype=torch.float32)
+    coef = torch.empty((B * it_matches * it_ransac, 2), device=dev, dtype=torch.float32)
+    flags = torch.zeros((2,), device=dev, dtype=torch.int32)
+    call("mk_train_aggregate_fwd", ptr(out), ptr(Rt), ptr(saved), B, it_matches, it_ransac, float(temperature), int(bool(add_null)),
+         float(null_loss), float(null_score), ptr(loss_value), ptr(per_pair), ptr(coef), ptr(flags), stream())
+    return loss_value, per_pair, coef, flags
+
+
+def train_aggregate_bwd(coef, g_pair, B, it_matches, it_ransac):
+    """mk_train_aggregate_bwd: dL/d(pair baseline) [B] -> dL/d(loss_k, score_k) [nhyp, 2] (the grad_out of train_tail_bwd)."""
+    coef, g_pair = _c(coef, g_pair.float())
+    g = torch.empty_like(coef)
+    call("mk_train_aggregate_bwd", ptr(coef), ptr(g_pair), B, it_matches, it_ransac, ptr(g), stream())
+    return g
+
+
+def gather_backproject_bwd(idx, corr, gX, gY, K0, K1, B, rows_per_pair, n0, n1):
+    """mk_gather_backproject_bwd: dL/dX, dL/dY [B*rows_per_pair, k, 3] -> (dL/dkps0 [B,2,n0], dL/ddepth0 [B,1,n0], dL/dkps1, dL/ddepth1)."""
+    idx, corr, gX, gY, K0, K1 = _c(idx, corr, gX, gY, K0, K1)
+    k = idx.shape[1]
+    buf = torch.zeros((B * 3 * (n0 + n1),), device=idx.device, dtype=torch.float32)   # one zero-fill for the four accumulators
+    gk0, gd0 = buf[:2 * B * n0].view(B, 2, n0), buf[2 * B * n0:3 * B * n0].view(B, 1, n0)
+    o = 3 * B * n0
+    gk1, gd1 = buf[o:o + 2 * B * n1].view(B, 2, n1), buf[o + 2 * B * n1:].view(B, 1, n1)
+    call("mk_gather_backproject_bwd", ptr(idx), ptr(corr), ptr(gX), ptr(gY), ptr(K0), ptr(K1), ptr(gk0), ptr(gd0), ptr(gk1), ptr(gd1),
+         B, rows_per_pair, k, n0, n1, stream())
+    return gk0, gd0, gk1, gd1
+
+
 def refine_pose(X, Y, Rh, th, score, B, it_matches, it_ransac, th_inlier, num_ref, min_inliers, invalid=None):
     X, Y, Rh, th, score = _c(X, Y, Rh, th, score)
     k = X.shape[1]

@@ -8,11 +8,13 @@ Where the work goes:
   * NUM_CORR_3d3d-point hypotheses and the <= NUM_REF_STEPS refinement rounds of all B*IT_MATCHES*IT_RANSAC hypotheses
     (:148-184, the no-grad block): `mk_train_ransac_masks`, one wave per hypothesis;
   * the REINFORCE scatter the reference runs as a python loop over B*IT_MATCHES rows (:251-261): `mk_reinforce_scatter`;
-  * the differentiable tail -- the final masked Procrustes of every hypothesis, its soft inlier score and its VCRE / pose
-    loss (:187-246) -- is a torch.autograd.Function whose forward AND backward are HIP kernels (`mk_train_tail_fwd` /
-    `mk_train_tail_bwd`: one wave per hypothesis, the 3x3 SVD differentiated in closed form);
-  * what is left to torch: the gather + back-projection of the sampled keypoints (:139-146) and the softmax aggregation over
-    the hypotheses of a set (tiny [B*IT_MATCHES, IT_RANSAC] tensors), so that `avg_loss.backward()` fills
+  * everything differentiable -- the gather + back-projection of the sampled keypoints (:139-146, `mk_gather_backproject` /
+    `mk_gather_backproject_bwd`), the final masked Procrustes of every hypothesis with its soft inlier score and VCRE / pose loss
+    (:187-227, `mk_train_tail_fwd` / `mk_train_tail_bwd`: one wave per hypothesis, the 3x3 SVD differentiated in closed form) and
+    the softmax aggregation over the hypotheses of a set and the sets of a pair (:229-246, `mk_train_aggregate_fwd` / `_bwd`) --
+    is ONE torch.autograd.Function (`_RansacLoss`) whose forward and backward are chains of HIP entry points;
+  * what is left to torch: autograd's bookkeeping around that one node and the batch-level lines of `RANSAC_vectorized`
+    (:287-333: means over B, the top-k curriculum mask), so that `avg_loss.backward()` fills
     outputs['kps0'|'kps1'|'depth0'|'depth1'].grad as the reference's trainer expects (lib/models/MicKey/model.py:101-128).
 
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
@@ -23,34 +25,42 @@ from . import ops
 from ._native import MickeyHipError
 
 
-def backproject_3d(uv, depth, K):
-    """reference utils/training_utils.py:7-22 (differentiable w.r.t. uv and depth)."""
-    ones = torch.ones((uv.shape[0], uv.shape[1], 1), device=uv.device, dtype=uv.dtype)
-    return depth * (torch.linalg.inv(K) @ torch.cat([uv, ones], -1).transpose(2, 1)).transpose(2, 1)
-
-
-class _RansacTail(torch.autograd.Function):
-    """reference loss_class.py:187-246 -- the masked Procrustes of every hypothesis, its soft inlier score and its loss -- as
-    two HIP entry points (mk_train_tail_fwd / mk_train_tail_bwd, csrc/mk_train_tail.hip): forward AND backward; the SVD is
-    differentiated in closed form.  Inputs that the reference detaches (mask, ground truth, intrinsics) get no gradient."""
+class _RansacLoss(torch.autograd.Function):
+    """reference loss_class.py:139-246 + :263-268 for all B * IT_MATCHES * IT_RANSAC hypotheses at once: gather + back-projection of
+    the sampled matches (:139-146), hypotheses + refinement (no grad, :148-184), the masked Procrustes / soft inlier score / loss of
+    every hypothesis (:187-227), the softmax aggregation over the hypotheses of a set and the sums over the sets of a pair
+    (:229-246, :263-268).  Forward = five HIP entry points (mk_gather_backproject, mk_train_ransac_masks, mk_train_tail_fwd,
+    mk_train_aggregate_fwd), backward = three (mk_train_aggregate_bwd, mk_train_tail_bwd, mk_gather_backproject_bwd): no ATen
+    arithmetic between the sampled indices and dL/d(kps, depth).  Differentiable inputs: kps0, depth0, kps1, depth1; what the
+    reference detaches (scores, mask, ground truth, intrinsics) gets no gradient."""
 
     @staticmethod
-    def forward(ctx, X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft):
-        out, Rt, saved = ops.train_tail_fwd(X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft)
-        ctx.save_for_backward(X, Y, mask, Rgt, tgt, K0, K1, Rt, saved)
-        ctx.cfg = (it_r, it_m, th, loss_type, soft)
-        loss_value, loss_rot, loss_trans, score = (out[:, i].contiguous() for i in range(4))
-        ctx.mark_non_differentiable(loss_rot, loss_trans, Rt, saved)
-        return loss_value, loss_rot, loss_trans, score, Rt, saved
+    def forward(ctx, kps0, depth0, kps1, depth1, scores, idx_outer, K0, K1, Rgt, tgt, Ko0, Ko1, cfg, idx_inner, rng):
+        it_m, it_r, S, nc, th_ref, nref, th3d, loss_type, soft, temp, add_null, null_loss, null_score = cfg
+        seed, offset, set_base = rng
+        B, n0, n1 = scores.shape
+        X, Y, w, corr = ops.gather_backproject(idx_outer, scores, kps0, depth0, kps1, depth1, K0, K1, it_m)
+        mask, idx_in, rounds = ops.train_ransac_masks(X, Y, w, it_r, th_ref, nref, nc, idx_in=idx_inner, seed=seed, offset=offset,
+                                                      set_base=set_base)
+        out, Rt, saved = ops.train_tail_fwd(X, Y, mask, Rgt, tgt, Ko0, Ko1, it_r, it_m, th3d, loss_type, soft)
+        loss_value, per_pair, coef, flags = ops.train_aggregate_fwd(out, Rt, saved, B, it_m, it_r, temp, add_null, null_loss, null_score)
+        ctx.save_for_backward(X, Y, mask, Rgt, tgt, Ko0, Ko1, Rt, saved, coef, corr, idx_outer, K0, K1)
+        ctx.cfg = (B, n0, n1, it_m, it_r, th3d, loss_type, soft)
+        extras = (loss_value, out, mask, idx_in, rounds, Rt, saved, flags)
+        # rotation / translation errors are LOGGING outputs (the reference logs them, model.py:151-171, and optimises avg_loss only):
+        # returned without a gradient -- backpropagating avg_loss_rot / avg_loss_trans raises instead of yielding a partial gradient
+        rot, trans = per_pair[:, 1].contiguous(), per_pair[:, 2].contiguous()
+        ctx.mark_non_differentiable(rot, trans, *extras)
+        return (per_pair[:, 0].contiguous(), rot, trans) + extras
 
     @staticmethod
-    def backward(ctx, g_loss, g_rot, g_trans, g_score, g_Rt, g_saved):
-        X, Y, mask, Rgt, tgt, K0, K1, Rt, saved = ctx.saved_tensors
-        it_r, it_m, th, loss_type, soft = ctx.cfg
-        zero = torch.zeros((Rt.shape[0],), device=X.device)
-        g = torch.stack([g_loss if g_loss is not None else zero, g_score if g_score is not None else zero], 1).float()
-        gX, gY = ops.train_tail_bwd(X, Y, mask, Rgt, tgt, K0, K1, it_r, it_m, th, loss_type, soft, Rt, saved, g)
-        return (gX, gY) + (None,) * 10
+    def backward(ctx, g_base, *unused):
+        X, Y, mask, Rgt, tgt, Ko0, Ko1, Rt, saved, coef, corr, idx_outer, K0, K1 = ctx.saved_tensors
+        B, n0, n1, it_m, it_r, th3d, loss_type, soft = ctx.cfg
+        g = ops.train_aggregate_bwd(coef, g_base, B, it_m, it_r)
+        gX, gY = ops.train_tail_bwd(X, Y, mask, Rgt, tgt, Ko0, Ko1, it_r, it_m, th3d, loss_type, soft, Rt, saved, g)
+        gk0, gd0, gk1, gd1 = ops.gather_backproject_bwd(idx_outer, corr, gX, gY, K0, K1, B, it_m, n0, n1)
+        return (gk0, gd0, gk1, gd1) + (None,) * 11
 
 
 class MetricPoseLoss(torch.nn.Module):
@@ -120,79 +130,57 @@ class MetricPoseLoss(torch.nn.Module):
         ncell = n * n
         it_m, it_r, S, nc = self.it_matches, self.it_RANSAC, self.num_samples_matches, self.num_corr_3d_3d
         Ro, Ri = B * it_m, B * it_m * it_r
-        rowp = matches.reshape(B, ncell).float()
+        scores = matches.float().contiguous()
+        rowp = scores.view(B, ncell)
         outputs = {"kps0": kps0, "kps1": kps1, "depth0": depth0, "depth1": depth1}
-        baseline = torch.zeros((B,), device=dev)
-        losses_rot = torch.zeros((B, 1), device=dev)
-        losses_trans = torch.zeros((B, 1), device=dev)
-        gradients, gradients_b = torch.zeros_like(rowp), torch.zeros_like(rowp)
         dbg = {}
 
         def bail():
-            out = (baseline, losses_rot, losses_trans, gradients, gradients_b, outputs, 0)
+            z = lambda *shape: torch.zeros(shape, device=dev)  # noqa: E731
+            out = (z(B), z(B, 1), z(B, 1), z(B, ncell), z(B, ncell), outputs, 0)
             return out + (dbg,) if return_debug else out
 
         call = self._calls
         self._calls += 1
+        pair_base = int(batch.get("pair_base", self._default_pair_base()))
         if idx_outer is None:
             # the sampler's own input scan raises `invalid` on NaN / inf / negative cells and on empty rows: the cases in
             # which the reference skips the loop (:118-124) or lands in its except branch (:263-270)
             invalid = torch.zeros((1,), device=dev, dtype=torch.int32)
-            idx_outer, cnt = ops.exprace_topk(rowp, it_m, S, seed=self.seed, offset=2 * call, invalid=invalid,
-                                              pair_base=int(batch.get("pair_base", self._default_pair_base())))
+            idx_outer, cnt = ops.exprace_topk(rowp, it_m, S, seed=self.seed, offset=2 * call, invalid=invalid, pair_base=pair_base)
             if int(invalid.item()) != 0 or int((cnt < S).any().item()) != 0:
                 print("Invalid matching matrix! Skip RANSAC loop.")
                 return bail()
-        idx_outer = idx_outer.to(device=dev, dtype=torch.int64)
-        pair_of_row = torch.arange(B, device=dev).repeat_interleave(it_m)
-        bo = pair_of_row.view(Ro, 1).expand(Ro, S)
-        i0, i1 = torch.div(idx_outer, n, rounding_mode="trunc"), idx_outer % n
-        cor0, cor1 = kps0[bo, :2, i0], kps1[bo, :2, i1]
-        d0, d1 = depth0[bo, :2, i0], depth1[bo, :2, i1]
-        weights = rowp[bo, idx_outer]
+        idx_outer = idx_outer.to(device=dev, dtype=torch.int32).contiguous()
         Rgt, tgt, K0, K1 = self.read_pose_parameters(batch)
-        X = backproject_3d(cor0, d0, K0[pair_of_row])
-        Y = backproject_3d(cor1, d1, K1[pair_of_row])
-        # hypotheses + refinement, no autograd (the reference wraps the same steps in torch.no_grad, :152-184)
-        mask, idx_in, rounds = ops.train_ransac_masks(
-            X.detach(), Y.detach(), weights, it_r, float(self.inlier_ref_th), self.num_ref_steps, nc, idx_in=idx_inner,
-            seed=self.seed, offset=2 * call + 1, set_base=int(batch.get("pair_base", self._default_pair_base())) * it_m)
-        # the differentiable tail (reference :187-246): masked Procrustes, soft inlier score and loss of every hypothesis,
-        # forward and backward in HIP; autograd continues from dL/dX, dL/dY into the back-projection above
         pair_b = lambda v, w: v.float().reshape(B, w).contiguous()  # noqa: E731
         vcre = self.loss_type == "VCRE"
-        loss_value_k, loss_rot_k, loss_trans_k, score_k, Rt, saved = _RansacTail.apply(
-            X, Y, mask, pair_b(Rgt, 9), pair_b(tgt, 3), pair_b(batch["Kori_color0"], 9) if vcre else None,
-            pair_b(batch["Kori_color1"], 9) if vcre else None, it_r, it_m, float(self.inlier_3d_th), 0 if vcre else 1,
-            bool(self.soft_clipping))
-        R, t = Rt[:, :9].reshape(Ri, 3, 3), Rt[:, 9:].reshape(Ri, 1, 3)
-        dbg.update(idx_outer=idx_outer, idx_inner=idx_in, inliers_final=mask, rounds=rounds, R=R, t=t)
-        if check_rank:
-            # torch.linalg.matrix_rank(H) == 1 (reference :190): singular values above max(S) * 3 * eps(fp32)
-            sv = saved[:, 18:21]
-            if int(((sv > sv[:, :1] * 3 * 1.1920929e-07).sum(1) == 1).sum().item()) > 0:
-                print("[ERROR]: Skipping RANSAC iteration due to rank matrix.")
-                return bail()
-        if not bool(torch.isfinite(Rt).all().item()):
+        cfg = (it_m, it_r, S, nc, float(self.inlier_ref_th), self.num_ref_steps, float(self.inlier_3d_th), 0 if vcre else 1,
+               bool(self.soft_clipping), float(self.score_temperature), bool(self.add_null_hypothesis), float(self.max_loss_null),
+               float(self.th_outliers * S))
+        baseline, losses_rot, losses_trans, loss_value, out_k, mask, idx_in, rounds, Rt, saved, flags = _RansacLoss.apply(
+            kps0, depth0, kps1, depth1, scores, idx_outer, pair_b(K0, 9), pair_b(K1, 9), pair_b(Rgt, 9), pair_b(tgt, 3),
+            pair_b(batch["Kori_color0"], 9) if vcre else None, pair_b(batch["Kori_color1"], 9) if vcre else None, cfg, idx_inner,
+            (self.seed, 2 * call + 1, pair_base * it_m))
+        if return_debug:
+            dbg.update(idx_outer=idx_outer.long(), idx_inner=idx_in, inliers_final=mask, rounds=rounds, R=Rt[:, :9].reshape(Ri, 3, 3),
+                       t=Rt[:, 9:].reshape(Ri, 1, 3))
+        # the two conditions under which the reference drops the iteration, read back in ONE synchronisation: a rank-one
+        # cross-covariance (torch.linalg.matrix_rank(H) == 1, :190, only when asked) and non-finite R / t (:225-227)
+        nonfinite, rank_one = flags.tolist()
+        if check_rank and rank_one > 0:
+            print("[ERROR]: Skipping RANSAC iteration due to rank matrix.")
+            return bail()
+        if nonfinite:
             print("[ERROR]: Skipping RANSAC iteration due to invalid values in R/t.")
             return bail()
-        loss_value_k, loss_rot_k, loss_trans_k, score_k = (v.reshape(Ro, it_r) for v in (loss_value_k, loss_rot_k, loss_trans_k, score_k))
-        sm = torch.softmax(score_k / self.score_temperature, -1)
-        # rotation / translation errors are LOGGING outputs here (the reference logs them, model.py:151-171, and optimises
-        # avg_loss only): the native tail returns them without a gradient, so they are aggregated with a DETACHED softmax --
-        # backpropagating avg_loss_rot / avg_loss_trans raises instead of silently yielding the partial gradient through `sm`
-        loss_rot = (loss_rot_k * sm.detach()).sum(-1).unsqueeze(-1)
-        loss_trans = (loss_trans_k * sm.detach()).sum(-1).unsqueeze(-1)
-        if self.add_null_hypothesis:
-            loss_value_k = torch.cat([loss_value_k, torch.full((Ro, 1), float(self.max_loss_null), device=dev)], -1)
-            score_k = torch.cat([score_k, torch.full((Ro, 1), float(self.th_outliers * S), device=dev)], -1)
-        loss_value = (loss_value_k * torch.softmax(score_k / self.score_temperature, -1)).sum(-1).unsqueeze(-1)
-        gradients, gradients_b = ops.reinforce_scatter(idx_outer, loss_value.detach().reshape(Ro), B, it_m, ncell)
-        losses_rot = loss_rot.reshape(B, it_m).sum(-1).unsqueeze(-1)
-        losses_trans = loss_trans.reshape(B, it_m).sum(-1).unsqueeze(-1)
-        baseline = loss_value.reshape(B, it_m).sum(-1)
-        dbg.update(loss_value=loss_value.detach(), score=score_k.detach())
-        out = (baseline, losses_rot, losses_trans, gradients, gradients_b, outputs, 1)
+        gradients, gradients_b = ops.reinforce_scatter(idx_outer, loss_value, B, it_m, ncell)
+        if return_debug:
+            score_k = out_k[:, 3].reshape(Ro, it_r)
+            if self.add_null_hypothesis:
+                score_k = torch.cat([score_k, torch.full((Ro, 1), float(self.th_outliers * S), device=dev)], -1)
+            dbg.update(loss_value=loss_value.reshape(Ro, 1), score=score_k)
+        out = (baseline, losses_rot.unsqueeze(-1), losses_trans.unsqueeze(-1), gradients, gradients_b, outputs, 1)
         return out + (dbg,) if return_debug else out
 
     def RANSAC_vectorized(self, batch, check_rank=False, idx_outer=None, idx_inner=None):

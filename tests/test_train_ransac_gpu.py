@@ -198,14 +198,24 @@ def test_metric_pose_loss_vs_reference_golden(name):
             "g_depth0": rel(outputs["depth0"].grad.cpu(), ref["g_depth0"]), "g_depth1": rel(outputs["depth1"].grad.cpu(), ref["g_depth1"])}
     print(name, {k: "%.2e" % v for k, v in errs.items()})
     assert torch.equal(outputs["mask_topk"].cpu(), ref["mask_topk"])
-    # measured on MI355X: avg_loss <= 1.5e-5, gradients <= 3.3e-4, avg_loss_rot <= 4.5e-4 (acos of a near-1 cosine),
-    # keypoint / depth gradients <= 2.4e-4 (fp32 torch.svd backward on the GPU vs on the CPU); bounds = 2x measured
-    for k, tol in (("avg_loss", 3e-5), ("gradients", 7e-4), ("avg_loss_rot", 1e-3), ("avg_loss_trans", 1e-5)):
+    # measured on MI355X (round 6: gather / back-projection / aggregation native, forward and backward): avg_loss <= 1.5e-7 (round 5,
+    # with that glue in ATen on the GPU: 1.5e-5), avg_loss_rot <= 1e-4 (acos of a near-1 cosine), keypoint / depth gradients
+    # <= 2.4e-4 (the small cases: closed-form SVD adjoint here vs fp32 torch.svd backward there; default case 3e-6); bounds = 2x measured.
+    # `gradients` = (sum of the row losses a cell saw - its count x the pair's MEAN row loss) / it_matches is a difference of nearly
+    # equal numbers (most rows of the default case sit at the null hypothesis' loss): one ulp of a row loss is ~1e-3 of it, so its
+    # bound stays loose -- the well-conditioned parts (the un-centred sums, the counts, the baseline) are pinned tightly below
+    for k, tol in (("avg_loss", 1e-5), ("gradients", 2e-3), ("avg_loss_rot", 1e-3), ("avg_loss_trans", 1e-5)):
         assert errs[k] <= tol, (k, errs[k])
     for k in ("g_kps0", "g_kps1", "g_depth0", "g_depth1"):
         assert errs[k] <= 5e-4, (k, errs[k])
     single = loss.single_iteration_RANSAC(to_dev(batch), False, ref["idx_outer"].to(DEV), ref["idx_inner"].to(DEV))
     assert torch.equal(single[4].cpu(), ref["s_gradients_b"])   # counts: exact
+    e2 = {"s_gradients": rel(single[3].cpu(), ref["s_gradients"]), "s_baseline": rel(single[0].cpu(), ref["s_baseline"].reshape(-1)),
+          "s_losses_rot": rel(single[1].cpu().reshape(-1), ref["s_losses_rot"].reshape(-1)),
+          "s_losses_trans": rel(single[2].cpu().reshape(-1), ref["s_losses_trans"].reshape(-1))}
+    print(name, {k: "%.2e" % v for k, v in e2.items()})
+    # (measured: 8e-8 / 1.2e-6 on the VCRE cases, 1.1e-5 on pose_err, whose loss carries the acos of a near-1 cosine)
+    assert e2["s_gradients"] <= 3e-5 and e2["s_baseline"] <= 3e-5 and e2["s_losses_rot"] <= 1e-3 and e2["s_losses_trans"] <= 1e-5, e2
 
 
 def test_metric_pose_loss_philox_end_to_end():

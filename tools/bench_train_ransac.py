@@ -80,7 +80,7 @@ def main():
     out = {"what": "MetricPoseLoss forward + backward (training-time RANSAC, SURVEY row N3)", "pairs": B, "keypoints": n,
            "ms_per_step": ms, "pairs_per_s": B / ms * 1e3, "avg_loss": float(avg.detach()), "valid": nvalid,
            "hip_stage_ms": {k: round(v, 3) for k, v in stages.items()},
-           "torch_remainder_ms (gather + back-projection + softmax aggregation, forward and backward, host launches)": round(ms - sum(stages.values()), 3)}
+           "remainder_ms (gather + back-projection and aggregation kernels, forward and backward; autograd and host launches)": round(ms - sum(stages.values()), 3)}
     if args.cpu_pairs > 0:
         cb = TO.synthetic_batch(args.cpu_pairs, args.n, seed=1, noise=0.12)
         g = torch.Generator().manual_seed(0)

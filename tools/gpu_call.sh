@@ -16,6 +16,7 @@ for step in "$@"; do
     sampler) timeout 300 python tools/bench_sampler.py 2>&1 | tail -12 | tee gpurun_out/${TAG}_bench_sampler.txt ;;
     gemm)    timeout 600 python tools/bench_gemm.py $arg 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_vs_hipblaslt.txt ;;
     gemmb1)  timeout 600 python tools/bench_gemm_b1.py 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_b1.txt ;;
+    train)   timeout 600 python tools/bench_train_ransac.py 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_train_ransac.json ;;
     persist) timeout 600 python tools/bench_persist.py 2>&1 | grep "M=" | tee gpurun_out/${TAG}_gemm_persistent.txt ;;
     lnfold)  timeout 600 python tools/bench_lnfold.py 2>&1 | tail -6 | tee gpurun_out/${TAG}_bench_lnfold.txt ;;
     attn)    timeout 300 python tools/bench_attn.py $arg 2>&1 | tail -4 | tee gpurun_out/${TAG}_bench_attn.txt ;;
