@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TF = 2500.0   # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0   # HBM3E spec, MI355X_MICROARCH.md
 H, W = 720, 540
-TRAFFIC_SOURCE = "profiles/r05_pmc_traffic.json"
+TRAFFIC_SOURCE = "profiles/pmc_traffic.json"   # written by tools/profile_round.sh; keyed by the kernel-source hash
 
 
 STAGE_ROLES = {"encoder_gemm": ("encoder_gemm",), "attention": ("attention",), "conv_gemm": ("conv_gemm",),
@@ -705,7 +705,7 @@ def main(argv=None):
         if prof is not None and prof.records:
             stages, by = prof.summary(ev_steps)
             roof = roofline_entry(stages, by, B, args.dtype, model)
-            if roof is not None:
+            if roof is not None and not args.lean:   # (--lean is what the rocprofv3 passes run: no probe kernel in their statistics)
                 # what the socket power limit lets through the matrix pipe ALONE on this box right now (register-resident
                 # pseudo-random bf16 operands, no memory traffic; mickey_hip_dev.h, LABNOTES R4.11): the ceiling of the MFMA
                 # instruction itself next to the 2.5 PFLOP/s spec that `frac` is quoted against.  Never `peak`.

@@ -290,8 +290,19 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
     const char* sV = sK + KV_TILE_BYTES;
 
     f32x16 s[QB][2];
+    // the peeled final tile with at most 32 valid keys (1939 tokens: 19): its second 32-key block is all padding -- P = 0 there,
+    // exactly -- so neither its scores nor its half of P.V are computed (round 6: 1/62 of the kernel's matrix work; adding the
+    // zeros changed no bit, leaving them out changes none)
+    const bool half_tile = LAST && (ntok & 63) != 0 && (ntok & 63) <= 32;   // wave-uniform
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (LAST && kb == 1 && half_tile) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[qb][1][r] = -1e30f;
+        continue;
+      }
       const int row = kb * 32 + j;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
       const int row = dt * 32 + j;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
+        if (LAST && s4 >= 2 && half_tile) break;   // keys 32..63 of the tile: P = 0
         const V8 vf = *(const V8*)(sV + row * 128 + swz8(row, s4 * 2 + hi) * 16);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) o[qb][dt] = Lp<T>::mma32(vf, pf[qb][s4], o[qb][dt]);
@@ -394,7 +406,6 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
     }
   }
 }
-
 // The same kernel on v_mfma_f32_16x16x32 (modes 4 / 5).  At the socket power limit the 16x16x32 shape gets ~15 % more flops
 // through the matrix pipe than 32x32x16 (tools/micro/mfma_power.hip: 2.05 vs 1.79 PFLOP/s on random bf16 operands), and this
 // kernel is bound by energy like the GEMMs.  Layout: S^T = K.Q^T in 16-key x 16-query blocks -- after the MFMA lane (n, g) =

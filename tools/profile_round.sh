@@ -101,10 +101,10 @@ for k, d in sorted(b.items()):
 json.dump(busy, open("%s/gpurun_out/%s_pmc_busy.json" % (R, TAG), "w"), indent=1)
 print(json.dumps({"traffic_roles": {k: v for k, v in roles.items() if "gemm" in k or "attention" in k}, "busy": busy["roles"]}, indent=1)[:3000])
 PY
-# the bench line LAST, with the traffic file of this very build in place (bench.py reads profiles/${TAG}_pmc_traffic.json when the
+# the bench line LAST, with the traffic file of this very build in place (bench.py reads profiles/pmc_traffic.json when the
 # source hash matches), so that the line carries roofline.traffic and the per-stage traffic
 cd $R
-cp gpurun_out/${TAG}_pmc_traffic.json profiles/r05_pmc_traffic.json   # (the file name bench.py reads: TRAFFIC_SOURCE)
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json   # (the file name bench.py reads: TRAFFIC_SOURCE)
 if [ -z "$SKIP_BENCH" ]; then
   timeout 900 python bench.py --steps $STEPS_BENCH --warmup 5 --detail gpurun_out/${TAG}_bench_detail.json 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_b32.json
 fi
