@@ -250,3 +250,74 @@ def test_invalid_scores_and_cpu_tensors():
     b["final_scores"][1, 2, 3] = float("nan")
     avg, outputs, grads, nvalid = loss(b)
     assert nvalid == 0 and float(grads[0].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("add_null", [True, False])
+def test_aggregate_forward_backward_vs_torch(add_null):
+    """mk_train_aggregate_fwd / _bwd against the reference's lines written in torch (loss_class.py:229-246, :263-268): row losses under
+    the softmax of score / temperature (+ the null-hypothesis column), rotation / translation errors under the softmax WITHOUT it,
+    the per-pair sums, d(row loss) / d(loss_k, score_k) through autograd, and the two flags (non-finite R / t; rank-one count)."""
+    from mickey_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, it_m, it_r, temp, null_loss, null_score = 3, 20, 20, 20.0, 0.8, 0.35 * 512
+    nh = B * it_m * it_r
+    out = torch.rand((nh, 4), generator=g)
+    out[:, 3] = out[:, 3] * 300.0                      # scores: soft inlier counts of up to 512 matches
+    Rt = torch.randn((nh, 12), generator=g)
+    saved = torch.rand((nh, 32), generator=g) + 0.5
+    saved[:, 18] += 2.0                                # singular values: descending, full rank ...
+    saved[7, 19:21] = 0.0                              # ... except two rank-one hypotheses
+    saved[nh - 3, 19:21] = 1e-9
+    lk, sk = out[:, 0].double().reshape(-1, it_r).requires_grad_(), out[:, 3].double().reshape(-1, it_r).requires_grad_()
+    sm = torch.softmax(sk / temp, -1)
+    rot = (out[:, 1].double().reshape(-1, it_r) * sm).sum(-1)
+    trans = (out[:, 2].double().reshape(-1, it_r) * sm).sum(-1)
+    if add_null:
+        lk2 = torch.cat([lk, torch.full((B * it_m, 1), null_loss, dtype=torch.float64)], -1)
+        sk2 = torch.cat([sk, torch.full((B * it_m, 1), null_score, dtype=torch.float64)], -1)
+    else:
+        lk2, sk2 = lk, sk
+    lv = (lk2 * torch.softmax(sk2 / temp, -1)).sum(-1)
+    gp = torch.randn((B,), generator=g)
+    (lv.reshape(B, it_m).sum(-1) * gp.double()).sum().backward()
+    loss_value, per_pair, coef, flags = ops.train_aggregate_fwd(out.to(DEV), Rt.to(DEV), saved.to(DEV), B, it_m, it_r, temp, add_null,
+                                                               null_loss, null_score)
+    assert rel(loss_value.cpu(), lv) < 2e-6
+    assert rel(per_pair[:, 0].cpu(), lv.reshape(B, it_m).sum(-1)) < 2e-6
+    assert rel(per_pair[:, 1].cpu(), rot.reshape(B, it_m).sum(-1)) < 2e-6 and rel(per_pair[:, 2].cpu(), trans.reshape(B, it_m).sum(-1)) < 2e-6
+    gout = ops.train_aggregate_bwd(coef, gp.to(DEV), B, it_m, it_r)
+    assert rel(gout[:, 0].cpu(), lk.grad.reshape(-1)) < 2e-6 and rel(gout[:, 1].cpu(), sk.grad.reshape(-1)) < 2e-5
+    assert flags.tolist() == [0, 2]
+    Rt[5, 4] = float("nan")
+    Rt[100, 11] = float("inf")
+    assert ops.train_aggregate_fwd(out.to(DEV), Rt.to(DEV), saved.to(DEV), B, it_m, it_r, temp, add_null, null_loss, null_score)[3].tolist() == [1, 2]
+
+
+def test_gather_backproject_backward_vs_autograd():
+    """mk_gather_backproject_bwd against torch autograd through the reference's gather + backproject_3d (loss_class.py:139-146,
+    training_utils.py:7-22) in fp64: keypoints drawn by many cells of many rows accumulate (atomics), untouched ones stay zero."""
+    from mickey_amd import ops
+    g = torch.Generator().manual_seed(29)
+    B, n, it_m, S = 2, 300, 3, 128
+    kps0, kps1 = torch.rand((B, 2, n), generator=g) * 500, torch.rand((B, 2, n), generator=g) * 500
+    d0, d1 = torch.rand((B, 1, n), generator=g) * 4 + 0.5, torch.rand((B, 1, n), generator=g) * 4 + 0.5
+    K0 = torch.tensor([[[590.0, 0.3, 270.0], [0, 588.0, 360.0], [0, 0, 1.0]]]).repeat(B, 1, 1)
+    K1 = torch.tensor([[[585.0, 0, 268.0], [0, 588.0, 355.0], [0, 0, 1.0]]]).repeat(B, 1, 1)
+    scores = torch.rand((B, n, n), generator=g)
+    idx = torch.stack([torch.randperm(n * n, generator=g)[:S] for _ in range(B * it_m)])
+    idx[:, :40] = idx[:, :40] // n * n + (idx[:, :40] % 7)                # many cells share the image-1 keypoints 0..6
+    gX, gY = torch.randn((B * it_m, S, 3), generator=g), torch.randn((B * it_m, S, 3), generator=g)
+    dv = lambda v: v.to(DEV)  # noqa: E731
+    X, Y, w, corr = ops.gather_backproject(dv(idx.int()), dv(scores), dv(kps0), dv(d0), dv(kps1), dv(d1), dv(K0), dv(K1), it_m)
+    got = ops.gather_backproject_bwd(dv(idx.int()), corr, dv(gX), dv(gY), dv(K0), dv(K1), B, it_m, n, n)
+    leaves = [t.double().requires_grad_() for t in (kps0, d0, kps1, d1)]
+    pair = torch.arange(B).repeat_interleave(it_m)
+    bo = pair.view(-1, 1).expand(-1, S)
+    i0, i1 = torch.div(idx, n, rounding_mode="trunc"), idx % n
+    Xr = mo.backproject(leaves[0][bo, :2, i0], leaves[1][bo, :2, i0], K0.double()[pair])
+    Yr = mo.backproject(leaves[2][bo, :2, i1], leaves[3][bo, :2, i1], K1.double()[pair])
+    assert rel(X.cpu(), Xr) < 2e-6 and rel(Y.cpu(), Yr) < 2e-6
+    ((Xr * gX.double()).sum() + (Yr * gY.double()).sum()).backward()
+    for have, leaf in zip(got, leaves):
+        assert have.shape == leaf.shape and rel(have.cpu(), leaf.grad) < 5e-6
+        assert bool(((leaf.grad == 0) == (have.cpu() == 0)).all())       # keypoints nobody drew: exactly zero
