@@ -253,7 +253,7 @@ int mk_gemm_set_tile(int mode) {
     g_deep = mode - 510;
     return MK_OK;
   }
-  if (mode == 600 || mode == 601) {   // dev: persistent tile loop of the 256x256 kernel on (where it applies) / off
+  if (mode >= 600 && mode <= 602) {   // dev: persistent tile loop of the 256x256 kernel wherever it applies / off / producers only (default)
     g_pp64_persist = mode - 600;
     return MK_OK;
   }

@@ -5,7 +5,11 @@
 
 namespace mk {
 namespace gemm {
-int g_pp64_persist = 0;   // dev (mk_gemm_set_tile 600 / 601): 0 = persistent tile loop where it applies, 1 = never
+// persistent tile loop of the dense encoder launches: 2 (default, mk_gemm_set_tile 602) = the producers (proj, fc2, patch embed: KIND 2 / 3),
+// 0 (600) = wherever it applies, consumers (qkv, fc1) too, 1 (601) = never.  Round 6, three alternating runs of the whole forward on one
+// box (profiles/r06u_persist_ab.txt): encoder GEMMs 76.6 ms per step with the producers only, 77.1 with all, 77.2 with none -- fc1 loses
+// 0.7 - 1.8 % to the tile loop on every box measured, qkv is level, proj gains 3 - 4 %, fc2 0.5 - 1 % (r05 / r06_gemm_persistent.txt).
+int g_pp64_persist = 2;
 namespace {
 
 // Ping-pong with FULL-LINE LDS-DMA pieces: 256x256 tile, 8 waves (wave-row g = wave>>2), LDS stages of K = 64
@@ -463,7 +467,7 @@ int launch_k(const GemmParams& p, int groups, hipStream_t st, int band_m) {
     const int nk = p.K / BK, grid = num_cus() & ~7;
     const bool ok = groups == 1 && p.npass <= 1 && (nk & 1) == 0 && nk >= 4 && grid >= 8 && ntm * ntn > grid &&
                     !(KIND == 1 && p.ln_stats && p.ln_nslot != 16);   // the consumer's statistics staging is built for 16 slots
-    if (g_pp64_persist != 1 && ok) return launch_k2<T, AMODE, KIND, true>(p, groups, st, band_m, grid);
+    if (g_pp64_persist != 1 && ok && !(g_pp64_persist == 2 && KIND == 1)) return launch_k2<T, AMODE, KIND, true>(p, groups, st, band_m, grid);
   }
   return launch_k2<T, AMODE, KIND, false>(p, groups, st, band_m, ntm * ntn);
 }

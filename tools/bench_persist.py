@@ -63,6 +63,6 @@ for name, (fn, N, K, a, w) in cases.items():
     tot[1] += on
     print("M=%d %-4s N=%4d K=%4d | one tile per workgroup %.3f ms (%4.0f TF) | persistent %.3f ms (%4.0f TF) %+5.1f %% | hipBLASLt bare %.3f ms (%4.0f TF) | persistent / bare %.2f"
           % (M, name, N, K, off * 1e3, fl / off / 1e12, on * 1e3, fl / on / 1e12, (off / on - 1) * 100, bl * 1e3, fl / bl / 1e12, bl / on), flush=True)
-ops.gemm_set_tile(600)
+ops.gemm_set_tile(602)   # back to the default (producers only)
 print("M=%d sum of the four (one encoder block's linears): %.3f -> %.3f ms (%+.1f %%); x 24 blocks = %.1f -> %.1f ms per step"
       % (M, tot[0] * 1e3, tot[1] * 1e3, (tot[0] / tot[1] - 1) * 100, tot[0] * 24e3, tot[1] * 24e3))
