@@ -12,15 +12,21 @@ the node has fewer than N GPUs.  ``n_gpus`` in the output is the number of ranks
 
 Rank 0 prints ONE COMPACT JSON line (< 3 KB: the driver keeps an 8-KB tail of stdout) as the LAST line of stdout with
   roofline     -- the dominant kernel (the 16-bit MFMA GEMM of the encoder linears): algorithmic FLOPs of
-                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s
+                  the launches in the timed region / their summed HIP-event durations, vs 2.5 PFLOP/s; `traffic` = HBM-side
+                  bytes per launch from the committed PMC passes of the same kernel sources (profiles/pmc_traffic.json: a
+                  per-source-hash constant); `peak_sustained` / `frac_sustained` = what the MFMA instruction alone
+                  sustained on this box straight after the timed region (mk_dev_mfma_sustained; information, never `peak`)
   stages       -- the six largest stages: ms per step and fraction of their governing peak
   cpu_baseline -- the CPU oracle (torch-CPU fp32 restatement of the reference) timed on this box's host
-                  cores on a bounded sample (1 pair; 1 warm-up + 1 timed run), N = 1 only
+                  cores on a bounded sample (1 pair; 1 warm-up, then the median of 3 runs; per-stage seconds), N = 1 only
+  sustained_60 -- the headline configuration over 60 back-to-back steps straight after the timed region, pairs/s
   value_ref_precision -- the same forward at the reference's literal precision split (fp16 ViT + fp32-grade heads,
                   mickey_extractor.py:49-56; leg `ref_split`), pairs/s
+  natural_operands -- the same forward on 1/f-spectrum images and massive-activation weights (leg `natural`): pairs/s and the
+                  encoder GEMM's TFLOP/s; information about the power limit, never `value`
   single_pair_ms -- BASELINE.json configs[1]: one 540x720 pair, hipGraph replay
 Everything else -- the full per-stage roofline list, every leg (--legs all: fp16 everywhere, ref_split, ref_split_fp32mfma,
-attn_mfma16, vit_small, config5), --sustained (60 steps), --include-h2d (PCIe-inclusive), --precision (errors vs the oracle
+attn_mfma16, vit_small, config5, natural), --include-h2d (PCIe-inclusive), --precision (errors vs the oracle
 outputs of the same run) -- goes to gpurun_out/bench_detail.json (--detail PATH) and is summarised on stderr.
 """
 import argparse
