@@ -224,23 +224,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 //     when a lane's share of a row sum exceeds 2^12: no per-tile maximum at all), 16 MFMAs per 32 x 64 tile (the matrix-pipe row sums of the lean kernel were a
 //     fifth of its matrix work: 805-825 -> 885 TFLOP/s when they went back to 32 fp32 adds);
 //   * QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and a workgroup covers 256 queries per staged tile.
+// One wave's share of a workgroup: QB sub-blocks of 32 queries from q0 on (all four waves stage K / V^T and meet at the barriers
+// whatever QB they run with: one barrier per KV tile in either instantiation).
 template <typename T, int QB>
-__global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                                              const T* __restrict__ vt, T* __restrict__ out,
-                                                                              int ldo, int heads, int ntok, int ntok_pad) {
+__device__ __forceinline__ void attn_fold_wave(const T* __restrict__ Qh, const T* __restrict__ Kh, const T* __restrict__ Vh,
+                                               T* __restrict__ out, int ldo, int img, int head, int ntok, int ntok_pad, char* smem,
+                                               int lane, int wave, int q0) {
   using V8 = typename Lp<T>::V8;
   using V4 = typename Lp<T>::V4;
-  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const AttnBlock ab = attn_block();
-  const int head = ab.head, img = ab.img;
-  const long long hb = (long long)img * heads + head;
-  const T* Qh = q + hb * ntok_pad * 64;
-  const T* Kh = k + hb * ntok_pad * 64;
-  const T* Vh = vt + hb * 64 * ntok_pad;
-  const int q0 = ab.qblk * (128 * QB) + wave * (32 * QB);
   const int j = lane & 31, hi = lane >> 5;
   const bool wave_has_queries = q0 < ntok;   // pad-only waves of the last query block stage K/V and keep the barriers, nothing else
 
@@ -406,6 +397,34 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(con
     }
   }
 }
+
+template <typename T, int QB, bool TAIL1 = true>   // TAIL1 = false: dev mode 6, the A/B partner without the one-sub-block tail wave
+__global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_fwd_fold_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                              const T* __restrict__ vt, T* __restrict__ out,
+                                                                              int ldo, int heads, int ntok, int ntok_pad) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // [stage][K | Vt]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const AttnBlock ab = attn_block();
+  const int head = ab.head, img = ab.img;
+  const long long hb = (long long)img * heads + head;
+  const T* Qh = q + hb * ntok_pad * 64;
+  const T* Kh = k + hb * ntok_pad * 64;
+  const T* Vh = vt + hb * 64 * ntok_pad;
+  const int q0 = ab.qblk * (128 * QB) + wave * (32 * QB);
+  if constexpr (QB == 2 && TAIL1) {
+    // the one wave per (image, head) whose SECOND 32-query sub-block is all padding (1939 tokens: queries 1920..1938 of the last
+    // block) runs the one-sub-block body: 1/62 of the kernel's matrix work, decided once per wave, outside the tile loop (as a
+    // wave-uniform `if` inside the loop it re-scheduled the whole loop: -5 %, profiles/r06r_attn_padding_skips.txt).  The
+    // 32- and 64-queries-per-wave bodies are bit-identical per query (tests/test_kernels_gpu.py)
+    if (q0 < ntok && q0 + 32 >= ntok) {
+      attn_fold_wave<T, 1>(Qh, Kh, Vh, out, ldo, img, head, ntok, ntok_pad, smem, lane, wave, q0);
+      return;
+    }
+  }
+  attn_fold_wave<T, QB>(Qh, Kh, Vh, out, ldo, img, head, ntok, ntok_pad, smem, lane, wave, q0);
+}
+
 // The same kernel on v_mfma_f32_16x16x32 (modes 4 / 5).  At the socket power limit the 16x16x32 shape gets ~15 % more flops
 // through the matrix pipe than 32x32x16 (tools/micro/mfma_power.hip: 2.05 vs 1.79 PFLOP/s on random bf16 operands), and this
 // kernel is bound by energy like the GEMMs.  Layout: S^T = K.Q^T in 16-key x 16-query blocks -- after the MFMA lane (n, g) =
@@ -611,6 +630,9 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
   else if (mode == 2)
     hipLaunchKernelGGL((attn_fwd_fold_kernel<T, 2>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
+  else if (mode == 6)
+    hipLaunchKernelGGL((attn_fwd_fold_kernel<T, 2, false>), dim3((ntok + 255) / 256, heads, nimg), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
   else if (mode == 4)
     hipLaunchKernelGGL((attn_fwd_fold16_kernel<T, 1>), dim3((ntok + 127) / 128, heads, nimg), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)vt, (T*)out, ldo, heads, ntok, ntok_pad);
@@ -625,7 +647,7 @@ void launch_attn(const void* q, const void* k, const void* vt, void* out, int ld
 }  // namespace
 
 extern "C" int mk_attn_set_mode(int mode) {
-  MK_CHECK_ARG(mode >= 0 && mode <= 5, "mk_attn_set_mode: 0 automatic, 1 / 2 = lean softmax with 32 / 64 queries per wave, 3 = classic online softmax, 4 / 5 = 1 / 2 on the 16x16x32 MFMA");
+  MK_CHECK_ARG(mode >= 0 && mode <= 6, "mk_attn_set_mode: 0 automatic, 1 / 2 = lean softmax with 32 / 64 queries per wave, 3 = classic online softmax, 4 / 5 = 1 / 2 on the 16x16x32 MFMA, 6 = 2 without the one-sub-block tail wave");
   g_attn_mode = mode;
   return MK_OK;
 }
