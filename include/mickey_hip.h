@@ -149,7 +149,9 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
 
 /* The same LayerNorm writing its rows as the (hi, lo) fp16 operand planes of the split-operand head kernels (mk_conv3x3_split,
  * mk_gemm_grouped_split; AMD.HEADS_DTYPE: split): LN(x) * plane_scale = hi + lo, both [.., ldo] fp16, dense or bordered as above
- * (no fp32 copy, no separate mk_split_planes pass).  sat_flag: see mk_split_planes. */
+ * (no fp32 copy, no separate mk_split_planes pass).  out_lo == NULL: only the hi plane is written -- the rows ROUNDED to fp16,
+ * what the reference's fp16 encoder hands its heads (mickey_extractor.py:49-52: forward_features(x.to(amp_dtype)) ... .float());
+ * a zero-initialised lo plane then stays zero.  sat_flag: see mk_split_planes. */
 int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
                         float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
                         int bord_h, int bord_w, int bord_m, int* sat_flag, mk_stream_t stream);
@@ -193,7 +195,8 @@ int mk_conv3x3(const void* in1, long long stride_in1, int C1, const void* in2, l
  * four planes a_hi, a_lo, w_hi, w_lo ONCE in LDS (one 128-byte row = 32 hi | 32 lo elements) and issues the three MFMA sets from
  * those fragments -- L2 -> LDS bytes and LDS fragment reads per product are 2/3 of three plain sweeps'.
  *   in1_hi / in1_lo, in2_hi / in2_lo: bordered fp16 feature maps (mk_split_planes of the fp32 maps, scale s_a); the two planes
- *      of a source must lie within 2 GiB of each other (one allocation);
+ *      of a source must lie within 2 GiB of each other (one allocation); in1_lo == NULL (then without in2): the source IS its
+ *      hi plane -- fp16 features of an fp16 encoder -- and hi_w . lo_a is not computed: two MFMA sets per K step instead of three;
  *   W: fp16 [Cout, 2 K], K = 9 C1 + C2: the BatchNorm-folded weights times s_w as INTERLEAVED planes -- for every block of 32
  *      K columns, 32 hi values then 32 lo values (weights.split_conv_weight); an identity shortcut is passed as in2 = the
  *      block input with identity columns in W;

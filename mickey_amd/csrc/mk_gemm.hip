@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {   // hi.hi, W_lo . A_hi, W_hi . A_lo
+        if (pr == 2 && p.npass == 2) break;   // the activations' lo plane is identically zero (mk_conv3x3_split, in1_lo == NULL)
 #pragma unroll
         for (int mi = 0; mi < WMF; ++mi)
 #pragma unroll
@@ -470,13 +471,16 @@ int mk_conv3x3_split(const void* in1_hi, const void* in1_lo, long long stride_in
                      long long strideBias, void* out, void* out_lo, int Cout, long long strideOut, int groups, int nimg, int H,
                      int Wd, int act, int out_bordered, float acc_scale, float plane_scale, int* sat_flag, mk_stream_t stream) {
   GemmParams p = {};
-  MK_CHECK_ARG(in1_hi && in1_lo && (!in2_hi == !in2_lo), "mk_conv3x3_split: every source needs both planes");
-  if (int e = split_source(in1_hi, in1_lo, p.A, p.pl1, "mk_conv3x3_split")) return e;
+  // in1_lo == NULL: the source IS its hi plane (features of an fp16 encoder: fp16 values) -- two products instead of three
+  const bool hi_only = in1_hi && !in1_lo;
+  MK_CHECK_ARG(in1_hi && (hi_only ? (!in2_hi && !in2_lo) : (!in2_hi == !in2_lo)),
+               "mk_conv3x3_split: every source needs both planes (in1_lo == NULL = an all-zero lo plane: then without in2)");
+  if (int e = split_source(in1_hi, hi_only ? in1_hi : in1_lo, p.A, p.pl1, "mk_conv3x3_split")) return e;
   if (in2_hi) {
     if (int e = split_source(in2_hi, in2_lo, p.A2, p.pl2, "mk_conv3x3_split")) return e;
   }
   p.W = W;
-  p.npass = 3; p.acc_scale = acc_scale;
+  p.npass = hi_only ? 2 : 3; p.acc_scale = acc_scale;
   p.M = nimg * H * Wd; p.N = Cout; p.K = 2 * (9 * C1 + (in2_hi ? C2 : 0));
   p.ldw = ldw; p.strideA_g = stride_in1; p.strideA2_g = stride_in2; p.strideW_g = strideW;
   p.strideBias_g = strideBias; p.strideOut_g = strideOut;

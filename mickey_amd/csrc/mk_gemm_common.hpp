@@ -30,7 +30,7 @@ struct GemmParams {
   // (hi, lo) from there (one of each pair is 0; the planes of a source lie within 2 GiB of each other: checked by the entry
   // points).  acc_scale undoes the power-of-two scaling of the planes in the epilogue.
   unsigned pl1[2], pl2[2];
-  int npass;           // 0 / 1: plain; 3: split operands
+  int npass;           // 0 / 1: plain; 3: split operands; 2: split operands whose activation lo plane is identically zero (two products)
   float acc_scale;
   // ... whose output feeds another split conv: written straight as the next conv's operand planes, out_lp = hi, out_lo = lo
   // (fp16, v * plane_scale = hi + lo) instead of fp32 rows + a separate mk_split_planes pass

@@ -47,8 +47,14 @@ namespace {
 // -- 96 MFMAs per wave on the 8 DMA pieces and 24 fragment reads that 64 MFMAs of a plain stage (or of one of the three
 // sweeps this replaces) take.  Ring hand-over is the plain kernel's with "last reader" = L2 for A and L1 for W: row g's
 // A(kt+2) pieces go out in its C2(kt) slot, one barrier behind its L2(kt); the same counted waits at the end of a stage.
-template <typename T, int AMODE, int KIND, bool PERSIST = false, bool SP = false>
+// SP2 (with SP): the activations' LO plane is identically zero -- the first conv of a head stack behind an fp16 encoder, whose
+// features ARE fp16 values in the reference (mickey_extractor.py:49-52: forward_features(x.to(amp_dtype)) ... .float()) -- so the
+// W_hi . A_lo product is not computed: TWO MFMA sets per stage in the plain kernel's four slots (the second load slot brings the
+// W_lo fragments only, the A_hi fragments stay).  The lo half of an A row in LDS is staged (from wherever the caller's lo offset
+// points: the hi plane) and never read.
+template <typename T, int AMODE, int KIND, bool PERSIST = false, bool SP = false, bool SP2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int band_m) {
+  static_assert(!SP2 || SP, "SP2 is a form of the split-operand kernel");
   static_assert(!PERSIST || AMODE == A_DENSE, "the persistent tile loop is built for dense operands");
   static_assert(!SP || (KIND == 0 && !PERSIST && sizeof(T) == 2), "split operands: plain epilogues, one tile per workgroup");
   constexpr int BKA = SP ? BK / 2 : BK;   // contraction columns of A per stage
@@ -236,6 +242,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   // sw / sa: the stage whose W / A pieces this stage issues -- kt + 1 / kt + 2, or (PERSIST, last two stages of a tile, woff /
   // aoff already re-pointed) stage 0 of the workgroup's NEXT tile; nk is even there, so the ring half is the same either way
   auto stage0 = [&](int kt, auto next1, auto next2, int sw, int sa, auto first) {
+    if constexpr (SP && SP2) {
+      bar();   // slot 4kt
+      load_frags(wf, xf, kt & 1, 0);
+      if constexpr (decltype(next1)::value) dma_w(sw);
+      bar();                      // slot 4kt+1
+      mfma32(wf, xf, No{}, 0, first);     // W_hi . A_hi
+      bar();                      // slot 4kt+2
+      load_w(wf, kt & 1, 1);              // W_lo; the A_hi fragments stay
+      bar();                      // slot 4kt+3
+      mfma32(wf, xf, next2, sa, No{});    // W_lo . A_hi
+      if constexpr (decltype(next2)::value)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed; A0(kt+2) may still fly
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     if constexpr (SP) {
       bar();                      // slot 6kt
       load_frags(wf, xf, kt & 1, 0);
@@ -271,6 +293,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto stage1 = [&](int kt, auto next1, auto next2, int sw, int sa, auto first) {
+    if constexpr (SP && SP2) {
+      bar();                      // slot 4kt+1
+      load_frags(wf, xf, kt & 1, 0);
+      if constexpr (decltype(next1)::value) dma_w(sw);
+      bar();                      // slot 4kt+2
+      mfma32(wf, xf, No{}, 0, first);
+      bar();                      // slot 4kt+3
+      load_w(wf, kt & 1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own share of stage kt+1 (A1 and W) landed
+      bar();                      // slot 4kt+4
+      mfma32(wf, xf, next2, sa, No{});
+      return;
+    }
     if constexpr (SP) {
       bar();                      // slot 6kt+1
       load_frags(wf, xf, kt & 1, 0);
@@ -432,19 +467,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p, int ban
   }
 }
 
-template <typename T, int AMODE, int KIND, bool PERSIST, bool SP = false>
+template <typename T, int AMODE, int KIND, bool PERSIST, bool SP = false, bool SP2 = false>
 int launch_k2(const GemmParams& p, int groups, hipStream_t st, int band_m, int grid) {
   constexpr int LDS = 2 * 512 * 128 + 256 * 8 + (PERSIST && KIND == 1 ? 16384 : 0);   // two stages + the folded LayerNorm's row parameters (+ the statistics' staging area)
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP, SP2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP>), dim3(grid, groups, 1), dim3(512), LDS, st, p, band_m);
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AMODE, KIND, PERSIST, SP, SP2>), dim3(grid, groups, 1), dim3(512), LDS, st, p, band_m);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -458,6 +493,9 @@ int launch_k(const GemmParams& p, int groups, hipStream_t st, int band_m) {
   // traffic as much and cost 1-6 % of time)
   if (band_m == 0) band_m = (AMODE == A_DENSE && ntn <= 4) ? -4 : 8;
   if constexpr (KIND == 0 && sizeof(T) == 2 && std::is_same<T, _Float16>::value) {
+    if (p.npass == 2) {   // split operands, activations' lo plane identically zero (conv only: mk_conv3x3_split with in1_lo == NULL)
+      if constexpr (AMODE == A_CONV3) return launch_k2<T, AMODE, 0, false, true, true>(p, groups, st, band_m, ntm * ntn);
+    }
     if (p.npass > 1) return launch_k2<T, AMODE, 0, false, true>(p, groups, st, band_m, ntm * ntn);   // split operands
   }
   if constexpr (AMODE == A_DENSE && KIND != 0) {   // (KIND 0: the plain epilogues -- head linears, patch embed of the unfolded

@@ -21,7 +21,7 @@ __device__ __forceinline__ void store_planes(void* hi, void* lo, long long o, co
     ol[e] = (_Float16)(sv - (float)oh[e]);
   }
   *(f16x4*)((_Float16*)hi + o) = oh;
-  *(f16x4*)((_Float16*)lo + o) = ol;
+  if (lo) *(f16x4*)((_Float16*)lo + o) = ol;   // lo == nullptr: the row rounded to fp16 (what an fp16 LayerNorm outputs)
 }
 
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048 (instantiated for 4 as well: D <= 1024 needs half the registers)
@@ -370,7 +370,7 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
 int mk_layernorm_planes(const float* x, int ldx, const float* w, const float* b, float eps, void* out_hi, void* out_lo, int ldo,
                         float plane_scale, float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows,
                         int bord_h, int bord_w, int bord_m, int* sat_flag, mk_stream_t stream) {
-  MK_CHECK_ARG(out_hi && out_lo, "mk_layernorm_planes: null plane pointer");
+  MK_CHECK_ARG(out_hi, "mk_layernorm_planes: null plane pointer");
   return layernorm_launch(x, ldx, w, b, eps, out_hi, ldo, 2, resid, ldr, rows_out, D, rows_per_img, skip, wgroup_rows, bord_h, bord_w,
                           bord_m, MK_F32, out_lo, plane_scale, sat_flag, stream);
 }

@@ -56,6 +56,17 @@ def resolve_heads_dtype(cfg, encoder_dtype):
     return _LP[v]
 
 
+def resolve_features_lp(cfg, lp_dtype):
+    """AMD.FEATURES_LP (split-operand heads only): the encoder's features reach the heads rounded to fp16, as in the reference, whose
+    fp16 encoder RETURNS fp16 tensors that `.float()` widens exactly (mickey_extractor.py:49-52).  auto (default) = True behind an
+    fp16 encoder (the reference's MICKEY.DINOV2.FLOAT16 data flow, literally), False otherwise; true / false force it (false: the
+    final LayerNorm's fp32 rows as (hi, lo) planes -- more precise than the reference, and a third product in the first conv)."""
+    v = str(cfg["AMD"].get("FEATURES_LP", "auto")).lower()
+    if v not in ("auto", "true", "false", "1", "0"):
+        raise ValueError("AMD.FEATURES_LP must be auto | true | false, got %r" % v)
+    return lp_dtype == torch.float16 if v == "auto" else v in ("true", "1")
+
+
 def resolve_heads_split(cfg):
     """AMD.HEADS_DTYPE: split -- the reference's precision split (fp32 heads behind a 16-bit encoder, mickey_extractor.py:49-56)
     at 16-bit matrix-core speed: head activations, LayerNorms and the small linears as in the fp32 mode, the 3x3
@@ -112,6 +123,7 @@ class MickeyRelativePose(nn.Module):
         self.lp_dtype = resolve_encoder_dtype(self.cfg)
         self.heads_dtype = resolve_heads_dtype(self.cfg, self.lp_dtype)
         self.heads_split = resolve_heads_split(self.cfg)
+        self.features_lp = self.heads_split and resolve_features_lp(self.cfg, self.lp_dtype)
         self.lean = bool(amd.get("LEAN", False))
         self.ln_fold = bool(amd.get("LN_FOLD", True))   # norm1 / norm2 folded into the GEMMs around them (16-bit modes)
         self.ln_centre = bool(amd.get("LN_CENTRE", True))   # ... with the residual stream kept row-centred
@@ -242,7 +254,7 @@ class MickeyRelativePose(nn.Module):
                 raise RuntimeError("FEATURE_MATCHER.DUAL_SOFTMAX.USE_DUSTBIN is set but the checkpoint has no %s (the "
                                    "reference's strict load fails on this too)" % DUSTBIN_KEY)
             self._dev_weights = weights.prepare(self._sd, self.cfg, dev, self.lp_dtype, heads_dtype=self.heads_dtype, heads_split=self.heads_split,
-                                                ln_fold=self.ln_fold, ln_centre=self.ln_centre)
+                                                ln_fold=self.ln_fold, ln_centre=self.ln_centre, features_lp=self.features_lp)
         return self._dev_weights
 
     # ---- forward ---------------------------------------------------------------------------------

@@ -148,8 +148,8 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
     if rows_out is None:
         rows_out = rows_in - skip * (rows_in // rows_per_img)
     if isinstance(out, (tuple, list)):   # (hi, lo) fp16 planes: the operand form of the split-operand head kernels
-        oh, ol = out
-        assert oh.dtype == torch.float16 and ol.dtype == torch.float16 and oh.stride() == ol.stride()
+        oh, ol = out   # ol None: the hi plane alone = the rows rounded to fp16 (mk_layernorm_planes)
+        assert oh.dtype == torch.float16 and (ol is None or (ol.dtype == torch.float16 and oh.stride() == ol.stride()))
         ldo = oh.stride(-2) if ldo is None else ldo
         bh, bw, bm = (bordered[1], bordered[2], bordered[0] * bordered[1] * bordered[2]) if bordered else (0, 0, 0)
         call("mk_layernorm_planes", ptr(x), x.stride(-2) if ldx is None else ldx, ptr(w), ptr(b), float(eps), ptr(oh), ptr(ol), ldo,
@@ -268,7 +268,8 @@ def conv3x3_split(in1, C1, w, bias, out, Cout, groups, nimg, H, W, act=ACT_NONE,
                   stride_w=0, stride_bias=0, stride_out=0, out_bordered=False, w_scale=SPLIT_W_SCALE, sat=None):
     """mk_conv3x3_split: in1 / in2 = (hi, lo) pairs of bordered fp16 planes (each pair one allocation: plane_pair), w fp16
     [.., Cout, 2 K] (weights.split_conv_weight); out: an fp32 tensor, or a (hi, lo) pair of fp16 planes = the operand form of
-    the next split conv (no fp32 round trip, no mk_split_planes pass)."""
+    the next split conv (no fp32 round trip, no mk_split_planes pass).  in1 = (hi, None): the source is its hi plane (fp16
+    features of an fp16 encoder): two products instead of three (then without in2)."""
     assert w.dtype == torch.float16
     h1, l1 = in1
     h2, l2 = in2 if in2 is not None else (None, None)

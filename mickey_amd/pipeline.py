@@ -100,11 +100,17 @@ def encoder_forward(W, ws, img):
     # geometries can share a row count while their border rows sit elsewhere)
     R = ops.bordered_rows(nimg, gh, gw)
     if getattr(W, "heads_split", False):
-        # split-operand heads: the final norm writes the convs' (hi, lo) fp16 operand planes directly (no fp32 feature map)
-        feat = ws.get_planes("feat_hl_%d_%d_%d" % (nimg, gh, gw), (R, D), dev, zero=True)
+        # split-operand heads: the final norm writes the convs' (hi, lo) fp16 operand planes directly (no fp32 feature map).
+        # features_lp (AMD.FEATURES_LP; automatic behind an fp16 encoder): the reference's heads receive what its fp16 encoder
+        # returns -- fp16 values, widened exactly by .float() (mickey_extractor.py:49-52) -- so only the hi plane is written (the rows
+        # rounded to fp16) and the lo plane of this buffer, zeroed at allocation, stays zero: the first conv of every head then runs
+        # two products instead of three (heads_forward)
+        flp = bool(getattr(W, "features_lp", False))
+        feat = ws.get_planes("feat_hl%s_%d_%d_%d" % ("_lp" if flp else "", nimg, gh, gw), (R, D), dev, zero=True)
     else:
         feat = ws.get("feat_%d_%d_%d" % (nimg, gh, gw), (R, D), getattr(W, "lp_heads", lp), dev, zero=True)
-    ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
+    hi_only = isinstance(feat, tuple) and bool(getattr(W, "features_lp", False))
+    ops.layernorm(x, W.norm_w, W.norm_b, 1e-6, out=(feat[0], None) if hi_only else feat, rows_out=nimg * npatch, rows_per_img=ntok, skip=1,
                   bordered=(nimg, gh, gw), sat=ws.sat_flag)
     return feat, gh, gw
 
@@ -144,7 +150,9 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
             # conv -> conv inside the stack: the epilogue writes the next conv's (hi, lo) operand planes directly (no fp32
             # round trip, no mk_split_planes pass); only the stack's output (read by the row-wise attention kernels) is fp32
             hp = plane_pair("rb%d_h" % bi, (G, R, co))
-            ops.conv3x3_split(xp, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in, w_scale=wsc(rb.w1), sat=sat,
+            # (the first block reads the feature map: with features_lp its lo plane is identically zero -- hi only, two products)
+            x1 = (xp[0], None) if bi == 0 and getattr(W, "features_lp", False) else xp
+            ops.conv3x3_split(x1, c_in, rb.w1, rb.b1, hp, co, G, nimg, gh, gw, act=ops.ACT_RELU, stride_in1=s_in, w_scale=wsc(rb.w1), sat=sat,
                               stride_w=rb.w1.shape[1] * rb.w1.shape[2], stride_bias=co, stride_out=R * co, out_bordered=True)
             xo = ws.get("rb%d_x" % bi + geo, (G, M, co), lp, dev) if last else plane_pair("rb%d_x" % bi, (G, R, co))
             ops.conv3x3_split(hp, co, rb.w2, rb.b2, xo, co, G, nimg, gh, gw, act=ops.ACT_RELU, in2=xp, C2=c_in, w_scale=wsc(rb.w2), sat=sat,

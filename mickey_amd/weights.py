@@ -141,7 +141,8 @@ def split_conv_weight_planes(planes):
     return v[..., 0, :].reshape(lead + (K2 // 2,)), v[..., 1, :].reshape(lead + (K2 // 2,))
 
 
-def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True, heads_split=False):
+def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=True, ln_centre=True, heads_split=False,
+            features_lp=False):
     """heads_dtype: operand type of the four head stacks (None = lp_dtype; torch.float32 = as the reference, which always
     runs them in fp32, mickey_extractor.py:53-56) while the encoder uses lp_dtype.  heads_split (with heads_dtype fp32): the
     3x3 convolutions -- 99 % of the heads' flops -- run on the 16-bit matrix cores with split fp16 operands
@@ -151,6 +152,7 @@ def prepare(sd, cfg, device, lp_dtype=torch.bfloat16, heads_dtype=None, ln_fold=
     dev = device
     W.lp_heads = lp_dtype if heads_dtype is None else heads_dtype
     W.heads_split = bool(heads_split)
+    W.features_lp = bool(features_lp) and W.heads_split   # the heads' input rounded to fp16 (pipeline.encoder_forward)
     assert not W.heads_split or W.lp_heads == torch.float32, "split-operand convs sit in the fp32 head pipeline"
 
 

@@ -169,9 +169,9 @@ def test_no_product_kernel_spills_registers():
             # the tile walk stay in scalar registers across both; none of the lane reads sits in the steady-state K loop)
             allowed = 400 if "lse_partial_kernelILb0E" in k["name"] else 64
             if "gemm_pp64_kernel" in k["name"]:
-                # template arguments parsed out of the mangled name -- <T, AMODE, KIND, PERSIST, SP> -- and a signature change must
+                # template arguments parsed out of the mangled name -- <T, AMODE, KIND, PERSIST, SP, SP2> -- and a signature change must
                 # fail HERE, not move a kernel into another bucket silently (round 5 keyed on the substring 'ELb1E')
-                m = re.search(r"gemm_pp64_kernelI(DF16b|DF16_)Li(\d)ELi(\d)ELb([01])ELb([01])EE", k["name"])
+                m = re.search(r"gemm_pp64_kernelI(DF16b|DF16_)Li(\d)ELi(\d)ELb([01])ELb([01])ELb([01])EE", k["name"])
                 assert m, "gemm_pp64_kernel's template signature changed: update this parser (%s)" % k["name"]
                 persist = m.group(4) == "1"
                 allowed = 144 if persist else 64   # measured: 68 - 137 in the persistent instantiations (tile loop around K loop +

@@ -848,6 +848,14 @@ def test_conv3x3_big_tiles_and_tiny_grids(nimg, H, W):
     assert rel(out2, ref2.permute(0, 2, 3, 1).reshape(M, Cout)) < 2e-5
 
 
+def _zero_lo_pair(xh, ops, dev):
+    """(hi, lo) planes in ONE allocation (what the split kernels address) with lo identically zero"""
+    h, l = ops.plane_pair(xh.shape, dev)
+    h.copy_(xh)
+    l.zero_()
+    return h, l
+
+
 @pytest.mark.parametrize("nimg,H,W,G,C1,C2,Cout,bordered", [(2, 9, 7, 3, 128, 64, 192, True),     # 128x128 tiles, shortcut source
                                                             (2, 9, 7, 2, 64, 0, 64, False),       # no second source, dense rows
                                                             (2, 9, 7, 2, 96, 32, 64, True),       # channel counts of 32-granularity
@@ -886,6 +894,7 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
         x2b = _to_bordered(x2, nimg, H, W)
         in2 = ops.split_planes(x2b, *ops.plane_pair(x2b.shape, dev))
     out = torch.full((G, R if bordered else M, Cout), 7.0, device=dev, dtype=torch.float32)
+    out_raw = out
     ops.conv3x3_split((xh, xl), C1, wsplit, bias, out, Cout, G, nimg, H, W, act=ops.ACT_RELU, in2=in2, C2=C2,
                       stride_in1=R * C1, stride_in2=0, stride_w=Cout * 2 * K, stride_bias=Cout, stride_out=out.shape[1] * Cout,
                       out_bordered=bordered)
@@ -921,6 +930,24 @@ def test_conv3x3_split_is_fp32_grade(nimg, H, W, G, C1, C2, Cout, bordered):
         ph, pl = ph[:, idx], pl[:, idx]
     back = (ph.double() + pl.double()) / ops.SPLIT_ACT_SCALE
     assert float((back - out.double()).abs().max()) <= 2.0 ** -21 * float(out.abs().max()) + 1e-7
+    # in1 = (hi, None): the source IS its hi plane (fp16 features of an fp16 encoder, AMD.FEATURES_LP): two products instead of
+    # three -- fp32-grade against an fp64 evaluation of those fp16 values, and equal to the three-product kernel fed a zero lo plane
+    if not C2:
+        out2 = torch.full_like(out_raw, 7.0)
+        ops.conv3x3_split((xh, None), C1, wsplit, bias, out2, Cout, G, nimg, H, W, act=ops.ACT_RELU, stride_in1=R * C1,
+                          stride_w=Cout * 2 * K, stride_bias=Cout, stride_out=out2.shape[1] * Cout, out_bordered=bordered)
+        out3 = torch.full_like(out_raw, 7.0)
+        ops.conv3x3_split(_zero_lo_pair(xh, ops, dev), C1, wsplit, bias, out3, Cout, G, nimg, H, W,
+                          act=ops.ACT_RELU, stride_in1=R * C1, stride_w=Cout * 2 * K, stride_bias=Cout, stride_out=out3.shape[1] * Cout,
+                          out_bordered=bordered)
+        assert torch.equal(out2, out3)
+        o2 = out2[:, idx] if bordered else out2
+        xhi = (xh.float() / ops.SPLIT_ACT_SCALE)[:, ops.bordered_index(nimg, H, W, dev)]      # the fp16 values, as dense rows
+        for gi in range(G):
+            xp = F.pad(xhi[gi].reshape(nimg, H, W, C1), (0, 0, 1, 1, 1, 1))
+            cols = torch.cat([xp[:, ky:ky + H, kx:kx + W].reshape(M, C1) for ky in range(3) for kx in range(3)], 1)
+            ref64 = F.relu(cols.double() @ w2d[gi].to(dev).double().t() + bias[gi].double())
+            assert rel(o2[gi], ref64) < 2e-6, (gi, rel(o2[gi], ref64))
 
 
 @pytest.mark.parametrize("M,N,K,lda", [(500, 128, 128, 256), (40000, 384, 128, 256), (40000, 256, 256, 256), (3000, 128, 256, 256),

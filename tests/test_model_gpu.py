@@ -113,25 +113,37 @@ def test_full_forward_golden(golden, cfg, dtype, heads):
 
 def test_heads_split_equals_heads_fp32(golden, cfg):
     """AMD.HEADS_DTYPE: split -- the reference's precision split (fp16 ViT, fp32 heads) with the heads' 3x3 convolutions on
-    split fp16 operands: same encoder, same fp32 head pipeline, so it must reproduce the exact-fp32-heads forward to fp32
-    round-off (the three-sweep products are fp32-grade), and with it sit inside the reference's own fp16 floor."""
+    split fp16 operands: same encoder, same fp32 head pipeline, so fed the SAME features (AMD.FEATURES_LP: false = the final
+    LayerNorm's fp32 rows) it must reproduce the exact-fp32-heads forward to fp32 round-off (the three products are fp32-grade), and
+    with it sit inside the reference's own fp16 floor.  With the default behind an fp16 encoder (FEATURES_LP auto = true: the
+    heads receive the features ROUNDED to fp16, which is what the reference's fp16 encoder returns, mickey_extractor.py:49-52; the
+    first conv of every head then runs two products) the outputs move by that one fp16 rounding of the features and stay inside the
+    same floor -- measured closer to the reference's fp16 golden than the unrounded variant is not required, inside the floor is."""
     dev = _dev()
     from mickey_amd import synthetic as syn
     g = golden("full_forward")
     batch = syn.synthetic_batch(B=2, H=182, W=196, seed=1234)
     outs = {}
-    for heads in ("fp32", "split"):
-        model, _ = _model(cfg, "fp16", HEADS_DTYPE=heads)
+    for name, amd in (("fp32", dict(HEADS_DTYPE="fp32")), ("split", dict(HEADS_DTYPE="split", FEATURES_LP=False)),
+                      ("split_lp", dict(HEADS_DTYPE="split"))):
+        model, _ = _model(cfg, "fp16", **amd)
+        assert model.features_lp == (name == "split_lp")
         data = {k: v.to(dev) for k, v in batch.items()}
         model.compute_correspondences(data)
-        outs[heads] = data
+        assert not model.heads_split or model.split_saturated() is False
+        outs[name] = data
     tol = tol_for(golden, torch.float16, "182")
     for k in KEYS:
         d = rel(outs["split"][k], outs["fp32"][k])
         e = rel(outs["split"][k], g[k])
-        print(k, "split vs fp32 heads %.2e   split vs reference %.2e (floor %.2e)" % (d, e, tol[k]))
+        dl = rel(outs["split_lp"][k], outs["split"][k])
+        el = rel(outs["split_lp"][k], g[k])
+        print(k, "split vs fp32 heads %.2e   split vs reference %.2e   fp16 features: vs split %.2e, vs reference %.2e (floor %.2e)"
+              % (d, e, dl, el, tol[k]))
         assert d < 2e-5, (k, d)
         assert e <= tol[k], (k, e, tol[k])
+        assert el <= tol[k], (k, el, tol[k])
+        assert dl <= tol[k], (k, dl, tol[k])   # one fp16 rounding of the features: a fraction of the fp16-encoder floor
 
 
 _ORACLE_720 = {}
