@@ -57,6 +57,8 @@ class _RansacLoss(torch.autograd.Function):
     def backward(ctx, g_base, *unused):
         X, Y, mask, Rgt, tgt, Ko0, Ko1, Rt, saved, coef, corr, idx_outer, K0, K1 = ctx.saved_tensors
         B, n0, n1, it_m, it_r, th3d, loss_type, soft = ctx.cfg
+        if g_base is None:   # the baseline did not take part in what was differentiated
+            return (None,) * 15
         g = ops.train_aggregate_bwd(coef, g_base, B, it_m, it_r)
         gX, gY = ops.train_tail_bwd(X, Y, mask, Rgt, tgt, Ko0, Ko1, it_r, it_m, th3d, loss_type, soft, Rt, saved, g)
         gk0, gd0, gk1, gd1 = ops.gather_backproject_bwd(idx_outer, corr, gX, gY, K0, K1, B, it_m, n0, n1)
