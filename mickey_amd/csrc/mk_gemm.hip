@@ -33,13 +33,10 @@ namespace {
 // SP: split operands staged once (mk_gemm_common.hpp, GemmParams): a K tile is 32 contraction columns, its LDS rows hold
 // [32 hi | 32 lo] -- sub-step 0 reads the HI fragments of W and A, sub-step 1 the LO fragments, and the three products
 // hi.hi, lo.hi, hi.lo come from those registers (the plain kernel's two sub-steps are the two K halves of a 64-column tile).
-// NSTAGE (0 = the default of the tile form): LDS stages.  4 stages of the 128x128 tile (129 KiB, one workgroup per CU; dev mode 3)
-// were built in round 6 for launches of <= one workgroup per CU (proj / fc2 of a single image pair: 248 tiles; 2/3 of the 64-row
-// form's L2 -> LDS bytes, three K tiles in flight) and measured NO faster: fc2 44.2 us against 41.7 (64x128, three stages), 45.5
-// (128x128, two stages) and hipBLASLt's 42.9 -- every form ends at ~760 TFLOP/s on this shape (profiles/r06k_gemm_b1.txt).  Kept
-// as the A/B partner, never chosen automatically.  The K loop visits the K tiles in the same order in every form: results are
-// bit-identical across them (tests/test_kernels_gpu.py::test_small_gemm_forms_are_bit_identical).
-template <typename T, int AMODE, int WMF, bool SP = false, int NSTAGE = 0>
+// (measured and removed in round 6: a 128x128 form with FOUR LDS stages -- 129 KiB, one workgroup per CU -- for launches of <= one
+// workgroup per CU, i.e. proj / fc2 of a single image pair: 2/3 of the 64-row form's L2 -> LDS bytes, three K tiles in flight, and NO
+// faster: fc2 44.2 us against 41.7 (64x128, three stages), 45.5 (128x128, two stages) and hipBLASLt's 42.9; profiles/r06k_gemm_b1.txt)
+template <typename T, int AMODE, int WMF, bool SP = false>
 __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   using V8 = typename Lp<T>::V8;
   constexpr int NWM = 2, NWN = 2;
@@ -50,9 +47,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   // and a launch lasts as long as ONE workgroup's K loop, which with two stages is one L2 -> LDS round trip (~1 us) per
   // K tile against ~0.15 us of MFMA work (fc2 of one pair: 64 tiles = 65 us).  Three stages keep two DMA stages in
   // flight behind the one being consumed (72 KiB: two workgroups per CU, i.e. four stages in flight per CU).
-  constexpr int NS = NSTAGE ? NSTAGE : (WMF == 2 ? 3 : 2);
+  constexpr int NS = WMF == 2 ? 3 : 2;
   constexpr int PIECES = AJ + WJ;   // LDS-DMA instructions per wave and stage
-  static_assert(NS >= 2 && NS <= 4 && PIECES * (NS - 2) < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NS stages][A tile | W tile], rows of 128 B
 
   const int tid = threadIdx.x;
@@ -70,9 +66,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   Stager<T, AMODE, NW, AJ, WJ, SP> st;
   st.init(p, g, m0, n0, wave, lane);
   st.issue(p, smem, smem + A_BYTES, 0);
-#pragma unroll
-  for (int s = 1; s < NS - 1; ++s)
-    if (s < nk) st.issue(p, smem + s * STAGE_BYTES, smem + s * STAGE_BYTES + A_BYTES, s);
+  if (NS == 3 && nk > 1) st.issue(p, smem + STAGE_BYTES, smem + STAGE_BYTES + A_BYTES, 1);
   // folded LayerNorm (consumer): row parameters of the tile into LDS while the first stage is in flight
   float2* lnp = (float2*)(smem + NS * STAGE_BYTES);
   if (AMODE == A_DENSE && p.ln_stats && tid < 2 * BM) ln_params_to_lds<BM, 2 * BM>(p, m0, tid, lnp, p.ln_shift_out != nullptr && n0 == 0);
@@ -83,9 +77,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = 0, nxt = NS - 1;   // stage buffers: being consumed / receiving stage kt + NS - 1
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed; with NS stages the pieces of stages kt + 1 .. kt + NS - 2 (those that exist) may still be in flight
-    if (NS >= 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-    else if (NS >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    // stage kt has landed; with three stages the pieces of stage kt + 1 (if it exists) may still be in flight
+    if (NS == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... for every wave, and everybody is done reading the buffer that is refilled next.  A bare s_barrier: __syncthreads()
     // is a workgroup fence and makes hipcc drain ALL LDS-DMA traffic (s_waitcnt vmcnt(0)) in front of it
@@ -144,13 +137,13 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel(GemmParams p) {
   epilogue<T, WMF>(p, acc, m0, n0, wm, wn, lane, g, lnp);
 }
 
-template <typename T, int AMODE, int WMF, bool SP = false, int NSTAGE = 0>
+template <typename T, int AMODE, int WMF, bool SP = false>
 int launch_small(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 32 * WMF;
-  constexpr int LDS = (NSTAGE ? NSTAGE : (WMF == 2 ? 3 : 2)) * (BM + 128) * 128 + BM * 8;   // the stages + the folded LayerNorm's row parameters
+  constexpr int LDS = (WMF == 2 ? 3 : 2) * (BM + 128) * 128 + BM * 8;   // the stages + the folded LayerNorm's row parameters
   static bool attr_done = false;  // benign race: the attribute call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, SP, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<T, AMODE, WMF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mk_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MK_ERR_LAUNCH;
@@ -158,7 +151,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
     attr_done = true;
   }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) / 128;
-  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, SP, NSTAGE>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gemm_kernel<T, AMODE, WMF, SP>), dim3(ntm * ntn, groups, 1), dim3(256), LDS, st, p);
   MK_CHECK_LAUNCH();
   return MK_OK;
 }
@@ -166,8 +159,7 @@ int launch_small(const GemmParams& p, int groups, hipStream_t st) {
 int g_num_cus = 0;
 int g_band_m = 0;      // tile order of the 256x256 kernels: 0 automatic, b > 0 bands of b m-tiles, -g groups of g n-tiles (dev: mk_gemm_set_tile 400 + b / 464 + g)
 int g_half_rows = 1;   // automatic choice may use the 64x128 tiling for under-filled launches (dev: 500 off / 501 on)
-int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 3 force 128x128 with 4 stages, 7 force the 8-wave ping-pong
-int g_deep = 0;        // dev 511: the automatic choice uses the 4-stage 128x128 form for launches of <= one workgroup per CU (measured slower: off)
+int g_schedule = 0;    // mk_gemm_set_tile: 0 automatic, 1 force 128x128, 2 force 64x128, 7 force the 8-wave ping-pong
 
 template <int AMODE>
 int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
@@ -194,12 +186,7 @@ int launch(const GemmParams& p, int groups, int dtype, hipStream_t st) {
   if (sched == 7) return launch_pp64(p, groups, dtype, AMODE, st, g_band_m);
   // 128x128 tiles fill a 256-CU part (2 workgroups per CU) from 512 tiles on; below that 64-row tiles double the count
   const long long small_tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * groups;
-  // ... and a launch of at most one 128x128 tile per CU keeps that tile with four LDS stages (dense 16-bit operands)
-  if constexpr (AMODE == A_DENSE) {
-    const bool deep = p.npass <= 1 && p.K >= 4 * BK && (g_schedule == 3 || (g_schedule == 0 && g_deep && small_tiles <= num_cus() && p.M > 64));
-    if (deep) return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 4, false, 4>(p, groups, st) : launch_small<_Float16, AMODE, 4, false, 4>(p, groups, st);
-  }
-  const bool half_rows = g_schedule == 2 || (g_schedule != 1 && g_schedule != 3 && g_half_rows && small_tiles < 2 * num_cus() && p.M > 64);
+  const bool half_rows = g_schedule == 2 || (g_schedule != 1 && g_half_rows && small_tiles < 2 * num_cus() && p.M > 64);
   if (p.npass > 1)   // split operands (fp16 planes)
     return half_rows ? launch_small<_Float16, AMODE, 2, true>(p, groups, st) : launch_small<_Float16, AMODE, 4, true>(p, groups, st);
   if (half_rows) return dtype == MK_BF16 ? launch_small<__bf16, AMODE, 2>(p, groups, st) : launch_small<_Float16, AMODE, 2>(p, groups, st);
@@ -250,16 +237,12 @@ int mk_gemm_set_tile(int mode) {
     g_half_rows = mode - 500;
     return MK_OK;
   }
-  if (mode == 510 || mode == 511) {   // dev: automatic use of the 4-stage 128x128 form off / on
-    g_deep = mode - 510;
-    return MK_OK;
-  }
   if (mode >= 600 && mode <= 602) {   // dev: persistent tile loop of the 256x256 kernel wherever it applies / off / producers only (default)
     g_pp64_persist = mode - 600;
     return MK_OK;
   }
-  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 7,
-               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 3 128x128 with 4 stages, 7 8-wave ping-pong)", mode);
+  MK_CHECK_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 7,
+               "mk_gemm_set_tile: unknown mode %d (0 automatic, 1 128x128, 2 64x128, 7 8-wave ping-pong)", mode);
   g_schedule = mode;
   return MK_OK;
 }

@@ -166,9 +166,8 @@ def test_persistent_gemm_is_bit_identical_short_k(D, K, last, dtype):
 @pytest.mark.parametrize("K,last", [(1024, False), (4096, False), (4096, True), (192, False)])
 def test_small_gemm_forms_are_bit_identical(K, last, dtype):
     """The producer GEMMs of ONE image pair (M = 3878: proj K = 1024, fc2 K = 4096, the last block's fp32 rows; K = 192 = three K
-    tiles, fewer than the deep form's stages) on every tile form the launcher can pick: 128x128 with two LDS stages (mode 1), 64x128
-    with three (2), 128x128 with FOUR (3: round 6's A/B form, profiles/r06k_gemm_b1.txt), the 256x256 ping-pong kernel (7) and
-    the automatic choice (0).  All walk the K tiles in the same order through the same epilogue: every output bit for bit -- which is
+    tiles) on every tile form the launcher can pick: 128x128 with two LDS stages (mode 1), 64x128 with three (2), the 256x256
+    ping-pong kernel (7) and the automatic choice (0).  All walk the K tiles in the same order through the same epilogue: every output bit for bit -- which is
     what keeps pair i of a batch equal to pair i alone whatever form its batch size selects."""
     from mickey_amd import ops
     dev = _dev()
@@ -190,7 +189,7 @@ def test_small_gemm_forms_are_bit_identical(K, last, dtype):
         return [x_out] if last else [hi, lo, st]
     try:
         ref = run(1)
-        for tile in (2, 3, 7, 0, 3):
+        for tile in (2, 7, 0, 2):
             for a_, b_ in zip(ref, run(tile)):
                 assert bool(torch.isfinite(b_.float()).all())
                 assert torch.equal(a_, b_), tile
@@ -198,7 +197,7 @@ def test_small_gemm_forms_are_bit_identical(K, last, dtype):
         ops.gemm_set_tile(0)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 7])
+@pytest.mark.parametrize("tile", [1, 2, 7])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (3878, 3072, 1024), (129, 64, 576), (1000, 132, 64), (20000, 1024, 256)])
 def test_gemm_bias_act(dtype, M, N, K, tile):
@@ -224,7 +223,7 @@ def test_gemm_bias_act(dtype, M, N, K, tile):
     assert torch.equal(out.cpu(), w.float()[:, :64].t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(3878, 1024, 4096), (700, 384, 256)])
 def test_gemm_ls_residual(M, N, K, tile):
     from mickey_amd import ops
