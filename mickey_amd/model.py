@@ -397,17 +397,33 @@ class MickeyRelativePose(nn.Module):
                 self._graphs.popitem(last=False)
         self._graphs.move_to_end(key)
         graph, static, gdata = entry
-        for k in self._GRAPH_INPUTS:
-            static[k].copy_(data[k], non_blocking=True)
+        # the four inputs go into the static buffers in ONE multi-tensor launch when they are fp32 device tensors already (the
+        # common case; a one-pair forward is ~330 kernels of 5.4 ms: every stray 5-us launch around the replay shows)
+        srcs = [data[k] for k in self._GRAPH_INPUTS]
+        if all(t.is_cuda and t.dtype == torch.float32 and t.device == dev for t in srcs):
+            torch._foreach_copy_([static[k] for k in self._GRAPH_INPUTS], srcs)
+        else:
+            for k in self._GRAPH_INPUTS:
+                static[k].copy_(data[k], non_blocking=True)
         self._calls += 1
         graph.replay()
         # everything the forward wrote is cloned out of the graph's pool (a later replay overwrites it); in LEAN mode only
         # what the inference callers read (submission.py:40-45, demo_inference.py:120-123): poses, confidence, depth / score
-        # maps and keypoints, plus final_scores (the one [B, n, n] matrix LEAN keeps) -- not the descriptors
+        # maps and keypoints, plus final_scores (the one [B, n, n] matrix LEAN keeps) -- not the descriptors.  The tensor
+        # copies are ONE multi-tensor launch per dtype instead of one launch per output (17 of them in the full mode)
         keep = self._LEAN_KEYS if self.lean else None
+        names, outs = [], []
         for k, v in gdata.items():
             if k not in self._GRAPH_INPUTS and (keep is None or k in keep):
-                data[k] = v.clone() if torch.is_tensor(v) else copy.copy(v)
+                if torch.is_tensor(v):
+                    names.append(k)
+                    outs.append(v)
+                else:
+                    data[k] = copy.copy(v)
+        fresh = [torch.empty_like(v) for v in outs]
+        torch._foreach_copy_(fresh, outs)
+        for k, t in zip(names, fresh):
+            data[k] = t
         return data["R"], data["t"]
 
     def forward(self, data, return_inliers=False):
