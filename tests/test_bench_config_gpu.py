@@ -33,8 +33,11 @@ def _auto_schedules():
         ops.attn_set_mode(0)
 
 
-def test_batch_invariance_of_the_benchmarked_forward(cfg):
-    """Pair i of a B = 32 forward == the B = 1 forward of pair i with pair_base = i: features, score matrices AND the pose
+@pytest.mark.parametrize("mode", ["headline", "ref_split"])
+def test_batch_invariance_of_the_benchmarked_forward(cfg, mode):
+    """(headline = bf16 encoder + fp16-operand heads; ref_split = the precision-matched leg: fp16 encoder, fp16 features, fp32-grade
+    heads on split operands -- its large convs run the 256x256 split kernels (two / three MFMA sets per stage), one pair the
+    128x128 ones.)  Pair i of a B = 32 forward == the B = 1 forward of pair i with pair_base = i: features, score matrices AND the pose
     (the samplers' Philox streams are keyed by the global pair index) -- with the schedules the launcher picks by itself:
     the one-pair run takes 128x128 / 64x128 GEMM tiles and the 32-queries-per-wave attention instantiation, the 32-pair run
     the 256x256 ping-pong GEMM and 64 queries per wave.  They agree bit for bit because every kernel family accumulates in one
@@ -45,9 +48,12 @@ def test_batch_invariance_of_the_benchmarked_forward(cfg):
     from mickey_amd.model import MickeyRelativePose
     dev = _dev()
     c = copy.deepcopy(cfg)
-    c["AMD"]["ENCODER_DTYPE"] = "bf16"
+    c["AMD"]["ENCODER_DTYPE"] = "bf16" if mode == "headline" else "fp16"
+    if mode == "ref_split":
+        c["AMD"]["HEADS_DTYPE"] = "split"
     c["AMD"]["GRAPH"] = False
     model = MickeyRelativePose(c)
+    assert model.heads_split == (mode == "ref_split") and model.features_lp == (mode == "ref_split")
     model.load_state_dict(syn.mickey_state_dict(c, seed=0))
     model = model.cuda()
     B = 32
@@ -67,6 +73,9 @@ def test_batch_invariance_of_the_benchmarked_forward(cfg):
         for k in keys:
             assert torch.equal(one[k][0], big[k][i]), (i, k, rel(one[k][0], big[k][i]))
         assert torch.equal(Ri[0], R[i]) and torch.equal(ti[0], t[i]) and torch.equal(one["inliers"][0], big["inliers"][i]), i
+    if mode != "headline":
+        assert model.split_saturated() is False
+        return
     # the classic online-softmax attention kernel (A/B partner) rounds differently: same pair to the 16-bit floor
     ops.attn_set_mode(3)
     one = {k: v[13:14].contiguous() for k, v in batch.items()}
