@@ -331,3 +331,44 @@ def test_split_operand_scheme_is_fp32_grade():
         ref = x.double() @ w.double().t()
         err = float((out - ref).norm() / ref.norm())
         assert err < 2e-6, (wmag, xmag, err)
+
+
+def test_natural_batch_statistics_and_determinism():
+    """synthetic.natural_batch (bench.py's `natural` leg): images in [0, 1] with a 1/f amplitude spectrum -- neighbouring pixels
+    correlated, unlike synthetic_batch's white noise -- same intrinsics, deterministic in the seed."""
+    import torch
+    from mickey_amd import synthetic as syn
+    a = syn.natural_batch(B=2, H=126, W=98, seed=7)
+    b = syn.natural_batch(B=2, H=126, W=98, seed=7)
+    c = syn.synthetic_batch(B=2, H=126, W=98, seed=7)
+    assert set(a) == set(c) and a["image0"].shape == (2, 3, 126, 98) and torch.equal(a["K_color0"], c["K_color0"])
+    assert torch.equal(a["image0"], b["image0"]) and not torch.equal(a["image0"], a["image1"])
+    assert float(a["image0"].min()) >= 0.0 and float(a["image0"].max()) <= 1.0 and 0.3 < float(a["image0"].mean()) < 0.6
+
+    def neighbour_corr(img):
+        x = img[:, :, :, :-1].reshape(-1) - img.mean()
+        y = img[:, :, :, 1:].reshape(-1) - img.mean()
+        return float((x * y).mean() / (x.std() * y.std()))
+    assert neighbour_corr(a["image0"]) > 0.6 and abs(neighbour_corr(c["image0"])) < 0.05
+
+
+def test_features_lp_resolution():
+    """AMD.FEATURES_LP: auto = fp16 features behind an fp16 encoder with split heads only (the reference's data flow,
+    mickey_extractor.py:49-52); explicit true / false; anything else is refused."""
+    import copy
+    import torch
+    from mickey_amd.config import default_cfg
+    from mickey_amd.model import MickeyRelativePose, resolve_features_lp
+    cfg = default_cfg()
+    assert resolve_features_lp(cfg, torch.float16) and not resolve_features_lp(cfg, torch.bfloat16)
+    for enc, heads, flp, want in (("fp16", "split", None, True), ("bf16", "split", None, False), ("fp16", "auto", None, False),
+                                  ("fp16", "split", False, False), ("bf16", "split", True, True)):
+        c = copy.deepcopy(cfg)
+        c["AMD"]["ENCODER_DTYPE"], c["AMD"]["HEADS_DTYPE"] = enc, heads
+        if flp is not None:
+            c["AMD"]["FEATURES_LP"] = flp
+        assert MickeyRelativePose(c).features_lp == want, (enc, heads, flp)
+    c = copy.deepcopy(cfg)
+    c["AMD"]["FEATURES_LP"] = "sometimes"
+    with pytest.raises(ValueError):
+        resolve_features_lp(c, torch.float16)
