@@ -168,6 +168,10 @@ class StageProfiler:
         timed("gemm_grouped", "head_gemm", lambda a, w, bias, out, groups, M, N, K, *r, **k:
               float(groups) * (M * K * esz(a) + N * K * esz(w) + M * N * esz(out)))
 
+        # Linear(-> 128) + LayerNorm (+ residual) in one pass: A and W read, the 16-bit rows written, the fp32 residual read + written
+        timed("gemm_ln128", "head_gemm", lambda a, w, ln_w, ln_b, eps, out, groups, M, K, lda=None, ldo=None, resid=None, bordered=None:
+              float(groups) * (M * K * esz(a) + 128 * K * esz(w) + M * 128 * (esz(out) + (8 if resid is not None else 0))))
+
         def ln_bytes(x, w, b, eps, out=None, out_dtype=None, resid=None, rows_out=None, **k):
             D = w.shape[-1]
             rows = rows_out if rows_out is not None else x.numel() // x.shape[-1]

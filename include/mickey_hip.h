@@ -147,6 +147,16 @@ int mk_layernorm(const float* x, int ldx, const float* w, const float* b, float 
                  float* resid, int ldr, int rows_out, int D, int rows_per_img, int skip, int wgroup_rows, int bord_h,
                  int bord_w, int bord_m, int dtype, mk_stream_t stream);
 
+/* A 128-wide linear and the LayerNorm behind it in one pass (the linear-attention layers of the heads: merge -> norm1 and
+ * mlp[2] -> norm2 + the layer's residual, att_layers/transformer_utils.py:58-66): per group g and row r
+ *   y = LayerNorm_128(A[g][r, :K] . W[g]^T) * ln_w[g] + ln_b[g];   resid != NULL: resid[g*M + r] += y, out = the updated resid
+ * A lp [groups][M, lda], W lp [groups][128, ldw] (no bias), ln_w / ln_b fp32 [groups, 128], resid fp32 [groups * M, ldr], out lp
+ * [groups * M, ldo] dense, or (bord_h > 0) a stack of bordered feature maps as in mk_layernorm.  K a multiple of 32, <= 256.  The
+ * fp32 GEMM output never reaches memory; K steps are summed in order (the accumulators are mk_gemm_grouped's, bit for bit). */
+int mk_gemm_ln128(const void* A, int lda, long long strideA, const void* W, int ldw, long long strideW, const float* ln_w,
+                  const float* ln_b, float eps, float* resid, int ldr, void* out, int ldo, int groups, int M, int K, int bord_h,
+                  int bord_w, int dtype, mk_stream_t stream);
+
 /* The same LayerNorm writing its rows as the (hi, lo) fp16 operand planes of the split-operand head kernels (mk_conv3x3_split,
  * mk_gemm_grouped_split; AMD.HEADS_DTYPE: split): LN(x) * plane_scale = hi + lo, both [.., ldo] fp16, dense or bordered as above
  * (no fp32 copy, no separate mk_split_planes pass).  out_lo == NULL: only the hi plane is written -- the rows ROUNDED to fp16,

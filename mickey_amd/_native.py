@@ -35,6 +35,7 @@ SIGNATURES = {
     "mk_im2col_patch14": ("i", "plliiiipiip"),
     "mk_cls_token": ("i", "pppiiip"),
     "mk_layernorm": ("i", "pippfpiipiiiiiiiiiip"),
+    "mk_gemm_ln128": ("i", "pilpilppfpipiiiiiiip"),
     "mk_layernorm_planes": ("i", "pippfppifpiiiiiiiiipp"),
     "mk_flash_attn_fwd": ("i", "ppppiiiiiip"),
     "mk_bordered_rows": ("l", "iii"),

@@ -262,6 +262,127 @@ __global__ __launch_bounds__(256) void dsc_tail_kernel(const float* __restrict__
   }
 }
 
+// ---- a 128-wide linear + LayerNorm (+ residual) in one pass (round 6) ----------------------------------------------------------
+// The linear-attention layers close two of their sub-blocks with `Linear(K -> 128, no bias)` followed by LayerNorm over those 128
+// features (reference att_layers/transformer_utils.py:58-66: merge -> norm1, mlp -> norm2 (+ the layer's residual)).  As two
+// launches the fp32 GEMM output [4 x 124 k rows, 128] is written and read back (254 + 254 MB, twice per layer); here a wave keeps
+// the 16 x 128 block of its 16 rows in the MFMA accumulators, normalises it there and writes only what the next kernel reads.
+//   workgroup = 4 waves x 16 rows; the group's W [128, K] stays in LDS (K <= 256: 64 KiB, chunk-swizzled: the fragment reads of 16
+//   lanes hit 16 different 16-byte bank groups) while the workgroup walks row tiles of its group; activations go from global memory
+//   straight into the MFMA B-operand registers (16 bytes per lane and K step).  Operands swapped as in the GEMM kernels (A-operand =
+//   W rows): a lane ends up with 4 consecutive features of ONE row per 16-feature block, 32 of the row's 128 values in all, the
+//   other 96 in lanes +16, +32, +48 -- the row statistics are two lane exchanges.  K steps are visited in order: the accumulators
+//   are those of the GEMM kernels bit for bit.  HBM-bound (MFMA work: 0.45 us per 64-row tile against ~4 us of its bytes).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_ln128_kernel(const T* __restrict__ A, int lda, long long strideA, const T* __restrict__ W,
+                                                            int ldw, long long strideW, const float* __restrict__ lnw,
+                                                            const float* __restrict__ lnb, float eps, float* __restrict__ resid, int ldr,
+                                                            T* __restrict__ out, int ldo, int groups, int M, int K, int bord_h, int bord_w) {
+  using V8 = typename Lp<T>::V8;
+  using V4 = typename Lp<T>::V4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // W: [K / 32][128 rows][64 B, chunk-swizzled] | ln weight [128] | ln bias [128]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.x % groups, wg = blockIdx.x / groups, nwg = gridDim.x / groups;
+  const int ks = K >> 5;
+  const T* Wg = W + (long long)g * strideW;
+  for (int i = threadIdx.x; i < 128 * ks * 4; i += 256) {   // 16-byte chunks, a W row's chunks consecutive
+    const int c = i & 3, s = (i >> 2) % ks, n = i / (4 * ks);
+    const uint4 v = *(const uint4*)(Wg + (long long)n * ldw + s * 32 + c * 8);
+    *(uint4*)(smem + ((s * 128 + n) * 64 + ((c ^ ((n >> 2) & 3)) << 4))) = v;
+  }
+  float* slw = (float*)(smem + 128 * K * 2);
+  float* slb = slw + 128;
+  if (threadIdx.x < 128) {
+    slw[threadIdx.x] = lnw[g * 128 + threadIdx.x];
+    slb[threadIdx.x] = lnb[g * 128 + threadIdx.x];
+  }
+  __syncthreads();
+  const int r16 = lane & 15, q = lane >> 4;
+  const int ntile = (M + 63) >> 6;
+  const long long brows = bord_h > 0 ? bordered_rows(M / (bord_h * bord_w), bord_h, bord_w) : 0;
+  // software pipeline over the workgroup's tiles: a tile's activations are requested while the previous tile is normalised and stored
+  // (into the registers its MFMAs have just released), its residual rows at the end of the previous epilogue
+  V8 xf[8];
+  f32x4 rv[8];
+  auto row_of = [&](int tile) { return tile * 64 + wave * 16 + r16; };   // this lane's row inside the group
+  auto load_x = [&](int tile) {
+    const int row = row_of(tile);
+    const T* ar = A + (long long)g * strideA + (long long)(row < M ? row : M - 1) * lda + q * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < ks) xf[s] = *(const V8*)(ar + s * 32);
+  };
+  auto load_r = [&](int tile) {
+    const int row = row_of(tile);
+    const float* rp = resid + ((long long)g * M + (row < M ? row : M - 1)) * ldr + q * 4;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) rv[f] = *(const f32x4*)(rp + f * 16);
+  };
+  if (wg < ntile) {
+    load_x(wg);
+    if (resid) load_r(wg);
+  }
+  for (int tile = wg; tile < ntile; tile += nwg) {
+    const int row = row_of(tile);
+    const bool ok = row < M;
+    const bool more = tile + nwg < ntile;   // workgroup-uniform
+    f32x4 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s >= ks) break;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int n = f * 16 + r16;
+        const V8 wf = *(const V8*)(smem + ((s * 128 + n) * 64 + ((q ^ ((n >> 2) & 3)) << 4)));
+        acc[f] = Lp<T>::mma16(wf, xf[s], acc[f]);
+      }
+    }
+    if (more) load_x(tile + nwg);
+    // LayerNorm over the row's 128 features: this lane's 32 + lanes ^16, ^32
+    float sm = 0.f;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) sm += (acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]);
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm * (1.0f / 128.0f);
+    float qs = 0.f;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[f][e] -= mean;
+        qs += acc[f][e] * acc[f][e];
+      }
+    }
+    qs += __shfl_xor(qs, 16, 64);
+    qs += __shfl_xor(qs, 32, 64);
+    const float rstd = 1.0f / sqrtf(qs * (1.0f / 128.0f) + eps);
+    if (ok) {
+      const long long grow = (long long)g * M + row;
+      const long long orow = bord_h > 0 ? (long long)g * brows + bordered_row(row, bord_h, bord_w) : grow;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int fe = f * 16 + q * 4;
+        const f32x4 ww = *(const f32x4*)(slw + fe), bb = *(const f32x4*)(slb + fe);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = acc[f][e] * rstd * ww[e] + bb[e];
+        if (resid) {
+          y += rv[f];
+          *(f32x4*)(resid + grow * ldr + fe) = y;
+        }
+        V4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (T)y[e];
+        *(V4*)(out + orow * ldo + fe) = o;
+      }
+    }
+    if (resid && more) load_r(tile + nwg);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -322,6 +443,42 @@ int mk_linattn_apply(const float* qkv, const float* kv, void* out, int ldo, int 
                        ldo, L, C);
   else
     hipLaunchKernelGGL(linattn_apply_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, qkv, kv, (float*)out, ldo, L, C);
+  MK_CHECK_LAUNCH();
+  return MK_OK;
+}
+
+int mk_gemm_ln128(const void* A, int lda, long long strideA, const void* W, int ldw, long long strideW, const float* ln_w,
+                  const float* ln_b, float eps, float* resid, int ldr, void* out, int ldo, int groups, int M, int K, int bord_h,
+                  int bord_w, int dtype, mk_stream_t stream) {
+  MK_CHECK_ARG(A && W && ln_w && ln_b && out, "mk_gemm_ln128: null pointer");
+  MK_CHECK_ARG(dtype == MK_BF16 || dtype == MK_F16, "mk_gemm_ln128: 16-bit operands only");
+  MK_CHECK_ARG(groups > 0 && M > 0 && K >= 32 && K <= 256 && K % 32 == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K &&
+                   ldo % 4 == 0 && ldo >= 128 && (!resid || (ldr % 4 == 0 && ldr >= 128)),
+               "mk_gemm_ln128: bad geometry (K a multiple of 32 up to 256, 128 output features)");
+  MK_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0 && ((uintptr_t)out & 7) == 0 && (strideA % 8) == 0 && (strideW % 8) == 0,
+               "mk_gemm_ln128: operands must be 16-byte aligned");
+  MK_CHECK_ARG(bord_h == 0 || (bord_w > 0 && M % (bord_h * bord_w) == 0), "mk_gemm_ln128: bordered output needs M = nimg * bord_h * bord_w");
+  const int lds = 128 * K * 2 + 1024;
+  const int ntile = (M + 63) / 64;
+  // workgroups per CU: two with a 64-KiB W (K = 256), three with 32 KiB (K <= 128: the registers' limit); each walks its share of a group's tiles
+  int per_group = ((K > 128 ? 2 : 3) * mk::gemm::num_cus() + groups - 1) / groups;
+  if (per_group > ntile) per_group = ntile;
+  const dim3 grid((unsigned)(per_group * groups));
+  hipError_t e = hipSuccess;
+  if (dtype == MK_BF16) {
+    static bool done = false;
+    if (!done) { e = hipFuncSetAttribute((const void*)gemm_ln128_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 2 + 1024); done = e == hipSuccess; }
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(gemm_ln128_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const __bf16*)A, lda, strideA, (const __bf16*)W,
+                         ldw, strideW, ln_w, ln_b, eps, resid, ldr, (__bf16*)out, ldo, groups, M, K, bord_h, bord_w);
+  } else {
+    static bool done = false;
+    if (!done) { e = hipFuncSetAttribute((const void*)gemm_ln128_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 2 + 1024); done = e == hipSuccess; }
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(gemm_ln128_kernel<_Float16>, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)A, lda, strideA,
+                         (const _Float16*)W, ldw, strideW, ln_w, ln_b, eps, resid, ldr, (_Float16*)out, ldo, groups, M, K, bord_h, bord_w);
+  }
+  if (e != hipSuccess) { mk_set_error("mk_gemm_ln128: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e)); return MK_ERR_LAUNCH; }
   MK_CHECK_LAUNCH();
   return MK_OK;
 }

@@ -168,6 +168,19 @@ def layernorm(x, w, b, eps, out=None, out_dtype=torch.bfloat16, resid=None, rows
     return out
 
 
+def gemm_ln128(a, w, ln_w, ln_b, eps, out, groups, M, K, lda=None, ldo=None, resid=None, bordered=None):
+    """mk_gemm_ln128: out = LayerNorm(a[g] @ w[g]^T) * ln_w[g] + ln_b[g] (+ resid, updated in place) for 128 output features;
+    a lp [groups, M, >= K], w lp [groups, 128, K], out lp (dense rows or, bordered = (nimg, H, W), bordered feature maps)."""
+    assert a.dtype == w.dtype == out.dtype and w.shape[-2] == 128 and w.shape[-1] == K
+    lda = a.stride(-2) if lda is None else lda
+    ldo = out.stride(-2) if ldo is None else ldo
+    bh, bw = (bordered[1], bordered[2]) if bordered else (0, 0)
+    call("mk_gemm_ln128", ptr(a), lda, a.stride(0) if a.dim() == 3 else 0, ptr(w), w.stride(-2), w.stride(0) if w.dim() == 3 else 0, ptr(ln_w), ptr(ln_b),
+         float(eps), ptr(resid), resid.stride(-2) if resid is not None else 128, ptr(out), ldo, groups, M, K, bh, bw, dtype_code(a.dtype),
+         stream())
+    return out
+
+
 def attn_set_mode(mode):
     """Dev knob (mickey_hip_dev.h): attention kernel variant, 0 = automatic (tests / benchmarks)."""
     call("mk_attn_set_mode", int(mode))

@@ -220,19 +220,28 @@ def heads_forward(W, ws, feat, nimg, gh, gw, cfg):
             ops.gemm_grouped(cat, lay.qkv_w, None, qkv, G, M, 3 * C, C, 2 * C, C, 3 * C, M * 2 * C, 3 * C * C, 0, M * 3 * C)
             ops.linattn_kv(qkv, kv, kvw, G, nimg, n, C)
             ops.linattn_apply(qkv, kv, msg, C, G, nimg, n, C)
-            ops.gemm_grouped(msg, lay.merge_w, None, mrg, G, M, C, C, C, C, C, M * C, C * C, 0, M * C)
-            ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
-                          wgroup_rows=M)
+            fused_ln = C == 128 and lp != torch.float32   # 16-bit operands: Linear(-> 128) + LayerNorm in one pass (mk_gemm_ln128)
+            if fused_ln:
+                ops.gemm_ln128(msg, lay.merge_w, lay.n1w, lay.n1b, 1e-5, cat[:, :, C:], G, M, C, ldo=2 * C)
+            else:
+                ops.gemm_grouped(msg, lay.merge_w, None, mrg, G, M, C, C, C, C, C, M * C, C * C, 0, M * C)
+                ops.layernorm(mrg, lay.n1w, lay.n1b, 1e-5, out=cat[:, :, C:], ldo=2 * C, rows_out=G * M, rows_per_img=G * M,
+                              wgroup_rows=M)
             ops.gemm_grouped(cat, lay.mlp0_w, None, hid, G, M, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C, M * 2 * C, 4 * C * C, 0,
                              M * 2 * C, act=ops.ACT_RELU)
-            ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
+            if not fused_ln:
+                ops.gemm_grouped(hid, lay.mlp2_w, None, mrg, G, M, C, 2 * C, 2 * C, 2 * C, C, M * 2 * C, 2 * C * C, 0, M * C)
         if split:   # the layer's output as operand planes: of the next layer's `cat`, or (last) of resblock4's bordered input
             o2 = (x4h, x4l) if last else (catp[0][:, :, :C], catp[1][:, :, :C])
         else:
             o2 = x4 if last else cat
-        ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=o2, ldo=C if last else 2 * C, resid=xs,
-                      rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None,
-                      sat=sat if split else None)
+        if not split and C == 128 and lp != torch.float32:   # (fused_ln above): mlp[2] + norm2 + the layer's residual in one pass
+            ops.gemm_ln128(hid, lay.mlp2_w, lay.n2w, lay.n2b, 1e-5, o2, G, M, 2 * C, ldo=C if last else 2 * C, resid=xs,
+                           bordered=(nimg, gh, gw) if last else None)
+        else:
+            ops.layernorm(mrg, lay.n2w, lay.n2b, 1e-5, out=o2, ldo=C if last else 2 * C, resid=xs,
+                          rows_out=G * M, rows_per_img=G * M, wgroup_rows=M, bordered=(nimg, gh, gw) if last else None,
+                          sat=sat if split else None)
     # ---- resblock4 ----
     kpw, dw = W.rb4_kp, W.rb4_dsc
     ck = kpw.cout

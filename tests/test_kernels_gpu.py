@@ -993,6 +993,64 @@ def test_grouped_gemm():
     assert rel(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,with_resid,bordered,nimg,H,W", [(128, False, False, 2, 9, 7), (256, True, False, 2, 9, 7), (256, True, True, 2, 9, 7),
+                                                            (128, False, False, 64, 51, 38), (256, True, True, 64, 51, 38)])
+def test_gemm_ln128_equals_gemm_then_layernorm(K, with_resid, bordered, nimg, H, W, dtype):
+    """mk_gemm_ln128 (round 6: Linear(K -> 128, no bias) + LayerNorm (+ residual) in one pass, the fp32 GEMM output never written)
+    against the two launches it replaces in the heads' linear-attention layers -- mk_gemm_grouped (fp32 out) then mk_layernorm with
+    per-group weights: the accumulators are the same (K steps in order), the row statistics are summed in another order -- fp32
+    round-off on the updated residual, at most one ulp of the 16-bit type on the written rows -- and against fp64; 4 groups, rows not
+    a multiple of the tile (126), dense and bordered output, the bench geometry (4 x 124032 rows)."""
+    from mickey_amd import ops
+    dev = _dev()
+    G, C = 4, 128
+    M = nimg * H * W
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    rn = lambda *shape, s=1.0: torch.randn(shape, device=dev, generator=gen) * s  # noqa: E731
+    a = rn(G, M, K, s=0.7).to(dtype)
+    w = rn(G, C, K, s=1.5 / math.sqrt(K)).to(dtype)
+    lw, lb = 1.0 + 0.3 * rn(G, C), 0.2 * rn(G, C)
+    res0 = rn(G, M, C) if with_resid else None
+    R = ops.bordered_rows(nimg, H, W)
+    ldo = C if bordered else 2 * C
+
+    def outbuf():
+        return torch.full((G, R if bordered else M, ldo), 7.0, device=dev, dtype=dtype)
+    # the two launches
+    mrg = torch.empty((G, M, C), device=dev, dtype=torch.float32)
+    ops.gemm_grouped(a, w, None, mrg, G, M, C, K, K, K, C, M * K, C * K, 0, M * C)
+    res_a = res0.clone() if with_resid else None
+    out_a = outbuf()
+    ops.layernorm(mrg, lw, lb, 1e-5, out=out_a, ldo=ldo, resid=res_a, rows_out=G * M, rows_per_img=G * M, wgroup_rows=M,
+                  bordered=(nimg, H, W) if bordered else None)
+    # one launch
+    res_b = res0.clone() if with_resid else None
+    out_b = outbuf()
+    ops.gemm_ln128(a, w, lw, lb, 1e-5, out_b, G, M, K, ldo=ldo, resid=res_b, bordered=(nimg, H, W) if bordered else None)
+    if bordered:
+        idx = ops.bordered_index(nimg, H, W, dev)
+        mask = torch.ones(R, dtype=torch.bool, device=dev)
+        mask[idx] = False
+        assert bool((out_b[:, mask] == 7.0).all())                       # border rows untouched
+        out_a, out_b = out_a[:, idx], out_b[:, idx]
+    else:
+        assert bool((out_b[:, :, C:] == 7.0).all())                      # the other half of the 2C-wide rows untouched
+        out_a, out_b = out_a[:, :, :C], out_b[:, :, :C]
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    d = (out_a.float() - out_b.float()).abs() / out_a.float().abs().clamp_min(1e-3)
+    assert float(d.max()) <= 1.01 * ulp and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+    if with_resid:
+        assert rel(res_b, res_a) < 2e-7
+    # fp64
+    y = torch.einsum("gmk,gnk->gmn", a.double(), w.double())
+    y = (y - y.mean(-1, keepdim=True)) / torch.sqrt(y.var(-1, unbiased=False, keepdim=True) + 1e-5) * lw.double()[:, None] + lb.double()[:, None]
+    if with_resid:
+        y = y + res0.double()
+        assert rel(res_b, y) < 2e-6
+    assert rel(out_b.float(), y) < (6e-4 if dtype == torch.float16 else 5e-3)
+
+
 def test_linear_attention_and_posenc():
     from mickey_amd import ops
     from oracle import mickey_oracle as O
