@@ -261,7 +261,8 @@ def test_encoder_launch_sequence_with_and_without_the_fold(monkeypatch):
                 pass
             fake = _Ops()
             for nm in ("gemm", "gemm_ls_residual", "gemm_qkv", "gemm_patch_embed", "gemm_ln", "gemm_qkv_ln", "gemm_ls_residual_ln",
-                       "gemm_patch_embed_ln", "flash_attn", "conv3x3", "conv3x3_split", "split_planes", "gemm_grouped_split", "gemm_grouped", "layernorm",
+                       "gemm_patch_embed_ln", "flash_attn", "conv3x3", "conv3x3_split", "split_planes", "gemm_grouped_split", "gemm_grouped", "gemm_ln128",
+                           "layernorm",
                        "dual_softmax", "sinkhorn",
                        "exprace_topk", "gather_backproject", "ransac_hypotheses", "refine_pose"):
                 setattr(fake, nm, lambda *a, **k: None)
